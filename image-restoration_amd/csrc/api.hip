@@ -1,0 +1,377 @@
+// extern "C" surface of libjirf_hip.so (declared in include/jirf_hip.h).  Every entry point
+// catches jirf::Failure and returns its code; nothing throws across the ABI.
+#include <cstring>
+#include <new>
+
+#include "runtime.h"
+
+using namespace jirf;
+
+struct jirf_net {
+  std::unique_ptr<Net> net;
+};
+
+namespace {
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const Failure& e) {
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    set_error("host allocation failed");
+    return JIRF_ENOMEM;
+  } catch (const std::exception& e) {
+    set_error("unexpected exception: %s", e.what());
+    return JIRF_EINVAL;
+  }
+}
+
+void require_gfx950(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  JIRF_REQUIRE(e == hipSuccess && n > 0, JIRF_ENOGPU, "no HIP device available (%s)",
+               e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+  JIRF_REQUIRE(device >= 0 && device < n, JIRF_EINVAL, "device %d out of range (have %d)", device, n);
+  hipDeviceProp_t prop;
+  JIRF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  JIRF_REQUIRE(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0, JIRF_ENOGPU,
+               "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+  JIRF_HIP_CHECK(hipSetDevice(device));
+}
+
+Net* get(jirf_net* n) {
+  JIRF_REQUIRE(n && n->net, JIRF_EINVAL, "null network handle");
+  return n->net.get();
+}
+const Net* get(const jirf_net* n) {
+  JIRF_REQUIRE(n && n->net, JIRF_EINVAL, "null network handle");
+  return n->net.get();
+}
+
+}  // namespace
+
+extern "C" {
+
+int jirf_abi_version(void) { return JIRF_ABI_VERSION; }
+
+int jirf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* jirf_last_error(void) { return last_error(); }
+
+jirf_net* jirf_net_create(const char* arch, const char* cfg_json, int device) {
+  jirf_net* out = nullptr;
+  const int rc = guarded([&] {
+    JIRF_REQUIRE(arch, JIRF_EINVAL, "null arch");
+    Config cfg;
+    cfg.obj = parse_json_object(cfg_json);
+    std::unique_ptr<Net> net;
+    if (!std::strcmp(arch, "HINT")) {
+      net = make_hint_net(cfg);
+    } else {
+      // define_network raises ValueError("<type> is not found.") (archs/__init__.py:39-40)
+      set_error("%s is not found.", arch);
+      throw Failure{JIRF_ENOTFOUND};
+    }
+    // construction is host-only (so the key layout can be inspected anywhere); the device is
+    // checked when the weights are uploaded
+    net->device = device;
+    out = new jirf_net{std::move(net)};
+    return JIRF_OK;
+  });
+  return rc == JIRF_OK ? out : nullptr;
+}
+
+void jirf_net_destroy(jirf_net* net) {
+  if (!net) return;
+  (void)hipDeviceSynchronize();
+  delete net;
+}
+
+int jirf_net_set_param(jirf_net* net, const char* key, const void* host_data, int dtype,
+                       const int64_t* shape, int ndim) {
+  return guarded([&] { return get(net)->set_param(key, host_data, dtype, shape, ndim); });
+}
+
+int jirf_net_param_count(const jirf_net* net) {
+  int n = -1;
+  guarded([&] {
+    n = (int)get(net)->params.size();
+    return JIRF_OK;
+  });
+  return n;
+}
+
+int jirf_net_param_info(const jirf_net* net, int index, const char** key_out, int64_t* shape_out,
+                        int* ndim_out) {
+  return guarded([&] {
+    const Net* n = get(net);
+    JIRF_REQUIRE(index >= 0 && index < (int)n->params.size(), JIRF_EINVAL, "param index %d out of range", index);
+    const ParamSpec& p = n->params[index];
+    JIRF_REQUIRE(p.shape.size() <= 4, JIRF_EINVAL, "param rank > 4");
+    if (key_out) *key_out = p.key.c_str();
+    if (ndim_out) *ndim_out = (int)p.shape.size();
+    if (shape_out)
+      for (size_t i = 0; i < p.shape.size(); ++i) shape_out[i] = p.shape[i];
+    return JIRF_OK;
+  });
+}
+
+int jirf_net_get_param(const jirf_net* net, const char* key, float* host_out, size_t n_floats) {
+  return guarded([&] {
+    const Net* n = get(net);
+    JIRF_REQUIRE(key && host_out, JIRF_EINVAL, "null argument");
+    const std::string k = n->canonical_key(key);
+    auto it = n->index.find(k);
+    JIRF_REQUIRE(it != n->index.end(), JIRF_ENOTFOUND, "%s has no parameter '%s'", n->arch.c_str(), key);
+    const ParamSpec& p = n->params[it->second];
+    JIRF_REQUIRE(p.is_set, JIRF_ESTATE, "parameter '%s' was never set", key);
+    JIRF_REQUIRE(n_floats >= p.host.size(), JIRF_EINVAL, "buffer too small for '%s'", key);
+    std::memcpy(host_out, p.host.data(), p.host.size() * 4);
+    return JIRF_OK;
+  });
+}
+
+int jirf_net_finalize(jirf_net* net) {
+  return guarded([&] {
+    Net* n = get(net);
+    JIRF_REQUIRE(!n->finalized, JIRF_ESTATE, "finalize called twice");
+    require_gfx950(n->device);
+    n->finalize();
+    return JIRF_OK;
+  });
+}
+
+int jirf_net_plan(jirf_net* net, int B, int H, int W, int batch_mode, size_t* workspace_bytes) {
+  return guarded([&] {
+    Net* n = get(net);
+    JIRF_HIP_CHECK(hipSetDevice(n->device));
+    const size_t bytes = n->plan(B, H, W, batch_mode);
+    if (workspace_bytes) *workspace_bytes = bytes;
+    return JIRF_OK;
+  });
+}
+
+int jirf_net_forward(jirf_net* net, const float* x, float* y, int B, int H, int W, int batch_mode,
+                     int on_device, void* stream) {
+  return guarded([&] {
+    Net* n = get(net);
+    JIRF_REQUIRE(x && y, JIRF_EINVAL, "forward: null input or output");
+    JIRF_REQUIRE(n->finalized, JIRF_ESTATE, "forward before finalize");
+    JIRF_HIP_CHECK(hipSetDevice(n->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (on_device) {
+      n->forward(x, y, B, H, W, batch_mode, s);
+      if (n->clock.enabled) n->clock.collect();
+      return JIRF_OK;
+    }
+    n->plan(B, H, W, batch_mode);
+    const size_t px = (size_t)B * H * W;
+    JIRF_HIP_CHECK(hipMemcpyAsync(n->stage_in, x, px * n->io_in_ch * 4, hipMemcpyHostToDevice, s));
+    n->forward(n->stage_in, n->stage_out, B, H, W, batch_mode, s);
+    JIRF_HIP_CHECK(hipMemcpyAsync(y, n->stage_out, px * n->io_out_ch * 4, hipMemcpyDeviceToHost, s));
+    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    if (n->clock.enabled) n->clock.collect();
+    return JIRF_OK;
+  });
+}
+
+int jirf_net_reset_cache(jirf_net* net) {
+  return guarded([&] {
+    get(net)->reset_cache();
+    return JIRF_OK;
+  });
+}
+int jirf_net_get_cache(jirf_net* net, float* host_out, int* n_out, int* c_out, size_t capacity_floats) {
+  return guarded([&] {
+    JIRF_REQUIRE(host_out && n_out && c_out, JIRF_EINVAL, "null argument");
+    return get(net)->get_cache(host_out, n_out, c_out, capacity_floats);
+  });
+}
+int jirf_net_set_cache(jirf_net* net, const float* host_in, int n, int c) {
+  return guarded([&] { return get(net)->set_cache(host_in, n, c); });
+}
+
+int jirf_net_attention_blocks(const jirf_net* net, int* n_blocks, int* channels_out, int capacity) {
+  return guarded([&] {
+    JIRF_REQUIRE(n_blocks, JIRF_EINVAL, "null argument");
+    return const_cast<Net*>(get(net))->attention_blocks(n_blocks, channels_out, capacity);
+  });
+}
+int jirf_net_get_perms(jirf_net* net, int32_t* host_out, size_t capacity_ints, size_t* n_ints) {
+  return guarded([&] {
+    JIRF_REQUIRE(host_out && n_ints, JIRF_EINVAL, "null argument");
+    return get(net)->get_perms(host_out, capacity_ints, n_ints);
+  });
+}
+int jirf_net_set_forced_perms(jirf_net* net, const int32_t* host_in, size_t n_ints) {
+  return guarded([&] { return get(net)->set_forced_perms(host_in, n_ints); });
+}
+
+int jirf_net_enable_kernel_timing(jirf_net* net, int enable) {
+  return guarded([&] {
+    get(net)->clock.enabled = enable != 0;
+    return JIRF_OK;
+  });
+}
+int jirf_net_kernel_times(jirf_net* net, const char** names_out, float* ms_out, double* flops_out,
+                          double* bytes_out, int* launches_out, int capacity, int* n_out) {
+  return guarded([&] {
+    Net* n = get(net);
+    JIRF_REQUIRE(n_out, JIRF_EINVAL, "null argument");
+    const auto& agg = n->clock.agg;
+    *n_out = (int)agg.size();
+    for (int i = 0; i < (int)agg.size() && i < capacity; ++i) {
+      if (names_out) names_out[i] = agg[i].name;
+      if (ms_out) ms_out[i] = agg[i].ms;
+      if (flops_out) flops_out[i] = agg[i].flops;
+      if (bytes_out) bytes_out[i] = agg[i].bytes;
+      if (launches_out) launches_out[i] = agg[i].launches;
+    }
+    return JIRF_OK;
+  });
+}
+
+// ---- single-kernel entry points -----------------------------------------------------------------
+
+int jirf_op_conv1x1(const float* x, const float* w_host, const float* bias_host, const float* res,
+                    float* y, int B, int Cin, int Cout, int P, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && w_host && y && B > 0 && Cin > 0 && Cout > 0 && P > 0, JIRF_EINVAL, "conv1x1: bad arguments");
+    WeightPool pool;
+    const PackedW w = pack_upload_1x1(pool, w_host, bias_host, Cout, Cin);
+    GemmArgs g{};
+    g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt; g.bias = w.bias;
+    g.x = tv(const_cast<float*>(x), (long)Cin * P);
+    g.y = tv(y, (long)Cout * P);
+    g.imgs_per_group = 1;
+    g.epi = res ? EP_RESID : EP_STORE;
+    g.r = tv(const_cast<float*>(res), (long)Cout * P);
+    launch_gemm(g, LD_PLAIN, static_cast<hipStream_t>(stream));
+    JIRF_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
+                       const float* w_host, float* y, int B, int Cin, int Cout, int P, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && ln_w && w_host && y && B > 0 && Cin > 0 && Cout > 0 && P > 0, JIRF_EINVAL, "ln_conv1x1: bad arguments");
+    JIRF_REQUIRE(ln_kind == 1 || ln_kind == 2, JIRF_EINVAL, "ln_conv1x1: ln_kind %d", ln_kind);
+    JIRF_REQUIRE(ln_kind == 2 || ln_b, JIRF_EINVAL, "ln_conv1x1: WithBias needs ln_b");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WeightPool pool;
+    const PackedW w = pack_upload_1x1(pool, w_host, nullptr, Cout, Cin);
+    DeviceBuffer stats;
+    stats.ensure((size_t)2 * B * P * 4);
+    float* mu = static_cast<float*>(stats.p);
+    float* rstd = mu + (size_t)B * P;
+    const TV xv = tv(const_cast<float*>(x), (long)Cin * P);
+    launch_ln_stats(xv, mu, rstd, B, Cin, P, s);
+    GemmArgs g{};
+    g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt;
+    g.x = xv; g.y = tv(y, (long)Cout * P); g.imgs_per_group = 1; g.epi = EP_STORE;
+    g.mu = mu; g.rstd = rstd; g.lnw = ln_w; g.lnb = ln_kind == 1 ? ln_b : nullptr; g.ln_center = ln_kind == 1;
+    launch_gemm(g, LD_LN, s);
+    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_conv3x3(const float* x, const float* w_host, const float* bias_host, const float* res,
+                    float* y, int B, int Cin, int Cout, int H, int W, int mode, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && w_host && y && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, JIRF_EINVAL, "conv3x3: bad arguments");
+    JIRF_REQUIRE(mode >= 0 && mode <= 2, JIRF_EINVAL, "conv3x3: mode %d", mode);
+    JIRF_REQUIRE(mode != 1 || (H % 2 == 0 && W % 2 == 0), JIRF_EINVAL, "conv3x3: unshuffle needs even H, W");
+    JIRF_REQUIRE(mode != 2 || Cout % 4 == 0, JIRF_EINVAL, "conv3x3: shuffle needs Cout %% 4 == 0");
+    WeightPool pool;
+    const PackedW w = pack_upload_3x3(pool, w_host, bias_host, Cout, Cin);
+    const long P = (long)H * W;
+    GemmArgs g{};
+    g.B = B; g.M = Cout; g.K = 9 * Cin; g.P = (int)P; g.Mpad = w.Mpad; g.wt = w.wt; g.bias = w.bias;
+    g.x = tv(const_cast<float*>(x), (long)Cin * P);
+    g.y = tv(y, (long)Cout * P);  // same element count in all three modes
+    g.H = H; g.W = W; g.Cin = Cin; g.imgs_per_group = 1;
+    g.epi = mode == 1 ? EP_UNSHUFFLE : mode == 2 ? EP_SHUFFLE : (res ? EP_RESID : EP_STORE);
+    g.r = tv(const_cast<float*>(res), (long)Cout * P);
+    launch_gemm(g, LD_CONV3, static_cast<hipStream_t>(stream));
+    JIRF_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int B, int C,
+                      int H, int W, int gate, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && w && y && B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "dwconv3x3: bad arguments");
+    const long P = (long)H * W;
+    launch_dwconv3x3(tv(const_cast<float*>(x), (long)C * P), w, bias, tv(y, (long)(gate ? C / 2 : C) * P), B, C, H, W,
+                     gate, static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_layernorm(const float* x, const float* w, const float* b, float* y, int B, int C, int P,
+                      int kind, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && w && y && B > 0 && C > 0 && P > 0, JIRF_EINVAL, "layernorm: bad arguments");
+    launch_layernorm(tv(const_cast<float*>(x), (long)C * P), w, b, tv(y, (long)C * P), B, C, P, kind,
+                     static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_hint_attention_core(const float* qkv, const float* params_host, const float* cache_in,
+                                int cache_c, float* out, float* tcache, int32_t* perm, float* att,
+                                float* cache_out, int B, int C, int P, int batch_mode,
+                                void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(qkv && params_host && out && tcache && perm && att && cache_out, JIRF_EINVAL,
+                 "hint_attention_core: null argument");
+    JIRF_REQUIRE(B > 0 && C >= 8 && P >= 2, JIRF_EINVAL, "hint_attention_core: bad shape");
+    JIRF_REQUIRE(!cache_in || cache_c > 0, JIRF_EINVAL, "hint_attention_core: cache size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const HintAttnShape sh = hint_attn_shape(B, C, P, batch_mode);
+    WeightPool pool;
+    HintAttnWeights w{};
+    const float* p = params_host;
+    w.temperature = pool.upload(p, 4);
+    p += 4;
+    for (int g = 0; g < 4; ++g) {
+      const int c = sh.gsz[g];
+      w.cw_w[g] = pool.upload(p, (size_t)2 * c * c); p += (size_t)2 * c * c;
+      w.cw_b[g] = pool.upload(p, (size_t)2 * c); p += 2 * c;
+      w.gc_w[g] = pool.upload(p, (size_t)c * c); p += (size_t)c * c;
+      w.gc_b[g] = pool.upload(p, (size_t)c); p += c;
+    }
+    HintAttnScratch sc;
+    DeviceBuffer scratch;
+    scratch.ensure(hint_attn_scratch_carve(sh, nullptr, &sc));
+    hint_attn_scratch_carve(sh, scratch.p, &sc);
+    const TV t = tv(const_cast<float*>(qkv), 3L * C * P);
+    launch_hint_attention(sh, tv_chan(t, 0, P), tv_chan(t, C, P), w, cache_in, cache_c, cache_out, sc,
+                          perm, nullptr, s);
+    GemmArgs g{};
+    g.B = B; g.M = C; g.K = C; g.P = P;
+    g.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+    g.wt = sc.att_t;
+    g.wt_bs = (long)((C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD) * g.Mpad;
+    g.x = tv_chan(t, 2 * C, P);
+    g.kidx = perm; g.imgs_per_group = B / sh.G;
+    g.y = tv(out, (long)C * P); g.y2 = tv(tcache, (long)C * P);
+    g.epi = EP_AV_INTRA; g.q = tv_chan(t, 0, P); g.k = tv_chan(t, C, P);
+    g.rq = sc.rq; g.rk = sc.rk;
+    launch_gemm(g, LD_GATHER, s);
+    JIRF_HIP_CHECK(hipMemcpyAsync(att, sc.att_nat, (size_t)B * C * C * 4, hipMemcpyDeviceToDevice, s));
+    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    return JIRF_OK;
+  });
+}
+
+}  // extern "C"

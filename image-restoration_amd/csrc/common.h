@@ -1,0 +1,169 @@
+// Shared host/device declarations of libjirf_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/jirf_hip.h"
+
+namespace jirf {
+
+// ---- error plumbing ---------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+struct Failure {
+  int code;
+};
+
+#define JIRF_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      jirf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                      __LINE__);                                                          \
+      throw jirf::Failure{JIRF_EHIP};                                                     \
+    }                                                                                     \
+  } while (0)
+
+#define JIRF_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      jirf::set_error(__VA_ARGS__);    \
+      throw jirf::Failure{code};       \
+    }                                  \
+  } while (0)
+
+// ---- tensor views ------------------------------------------------------------------------
+// A planar activation: element (b, c, p) lives at ptr[b * bs + c * P + p]; a view may be a
+// channel slice of a wider buffer (concat-free skips), hence the explicit batch stride.
+struct TV {
+  float* p = nullptr;
+  long bs = 0;
+};
+inline TV tv(float* p, long bs) { return TV{p, bs}; }
+inline TV tv_chan(TV t, long c, long P) { return TV{t.p + c * P, t.bs}; }
+
+// ---- GEMM family ---------------------------------------------------------------------------
+// Y[b][o][p] = epi( sum_k Wt[b][k][o] * Xk[b][k][p] ).  Wt is the K-major packed weight
+// (rows padded to GEMM_KPAD with zeros, row length Mpad padded to GEMM_MPAD).
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_KPAD = 16;
+constexpr int GEMM_MPAD = 128;
+
+enum GemmLoader : int {
+  LD_PLAIN = 0,   // X[b][k][p]
+  LD_GATHER = 1,  // X[b][kidx[g][k]][p]
+  LD_LN = 2,      // (X[b][k][p] - mu[b][p]) * rstd[b][p] * lnw[k] + lnb[k]
+  LD_CONV3 = 3,   // implicit 3x3: k = tap * Cin + c, X[b][c][y+dy][x+dx], zero padded
+};
+
+enum GemmEpi : int {
+  EP_STORE = 0,      // y = acc + bias
+  EP_RESID = 1,      // y = acc + bias + R
+  EP_GELU_MUL = 2,   // y = gelu(acc + bias) * AUX
+  EP_AV_INTRA = 3,   // y = acc; y2 = acc + q[perm[o]] * rq[perm[o]] + k[perm[o]] * rk[perm[o]]
+  EP_UNSHUFFLE = 4,  // conv3x3 then pixel-unshuffle(2)
+  EP_SHUFFLE = 5,    // conv3x3 then pixel-shuffle(2)
+};
+
+struct GemmArgs {
+  // problem
+  int B, M, K, P;        // M = Cout, K = reduction length (Cin or 9*Cin), P = pixels per image
+  int Mpad;              // packed row length of Wt
+  const float* wt;       // [Kpad][Mpad]
+  long wt_bs;            // batch stride of wt (0: shared)
+  const float* bias;     // [M] or null
+  TV x;                  // input activation
+  TV y;                  // output
+  // loader extras
+  const int* kidx;       // LD_GATHER: [G][K] row indices
+  int imgs_per_group;    // LD_GATHER / EP_AV_INTRA: images sharing one index row
+  const float* mu;       // LD_LN: [B][P]
+  const float* rstd;     // LD_LN: [B][P]
+  const float* lnw;      // LD_LN: [K]
+  const float* lnb;      // LD_LN: [K] or null (BiasFree: mu is also ignored)
+  int ln_center;         // LD_LN: subtract mu (WithBias) or not (BiasFree)
+  int H, W, Cin;         // LD_CONV3 geometry
+  // epilogue extras
+  int epi;
+  TV r;                  // EP_RESID residual / EP_GELU_MUL aux
+  TV y2;                 // EP_AV_INTRA second output
+  TV q, k;               // EP_AV_INTRA sources (unsorted q, k planes)
+  const float* rq;       // EP_AV_INTRA: [B][C] reciprocal norms of q
+  const float* rk;       // EP_AV_INTRA: [B][C]
+};
+
+void launch_gemm(const GemmArgs& a, int loader, hipStream_t s);
+// host-side packers (return Kpad; out is resized to Kpad * Mpad)
+int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad);
+int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad);
+
+// ---- memory-bound kernels -------------------------------------------------------------------
+void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
+                      hipStream_t s);
+void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s);
+void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
+                      int gate, hipStream_t s);
+
+// ---- HINT channel attention ------------------------------------------------------------------
+struct HintAttnShape {
+  int B, C, P;
+  int G;               // statistic groups: B (per image) or 1 (coupled)
+  int gsz[4], goff[4]; // channel-group sizes / offsets in sorted order
+  int splits;          // pixel splits of the statistics kernel
+};
+HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode);
+
+struct HintAttnWeights {   // device pointers, reference layouts
+  const float* temperature;             // [4]
+  const float* cw_w[4];                 // conv_width.weight [2c][c]
+  const float* cw_b[4];                 // [2c]
+  const float* gc_w[4];                 // gating_conv.weight [c][c]
+  const float* gc_b[4];                 // [c]
+};
+
+struct HintAttnScratch {   // device scratch, carved by hint_attn_scratch_carve
+  double* gram_part;   // [G][splits][C][C]
+  float* qk_part;      // [B][splits][C][C]
+  double* qsum_part;   // [G][splits][C]
+  float* q2_part;      // [B][splits][C]
+  float* k2_part;      // [B][splits][C]
+  float* qmean;        // coupled mode only: [C][P] batch mean of q
+  double* sim;         // [G][C] mean similarity
+  float* s_qk;         // [B][C][C]
+  float* rq;           // [B][C] reciprocal L2 norms of the q rows
+  float* rk;           // [B][C]
+  float* att_t;        // [B][Kpad][Mpad] block-diagonal attention, transposed (GEMM weight layout)
+  float* att_nat;      // [B][C][C] block-diagonal attention, natural orientation
+  float* pooled;       // [G][C][C] carried cache pooled to this block's C
+};
+// Lays the scratch out from `base` (may be null to size it) and returns the bytes needed.
+size_t hint_attn_scratch_carve(const HintAttnShape& sh, void* base, HintAttnScratch* out);
+
+// Runs regroup statistics -> permutation -> per-group softmax -> inter-modulation -> cache
+// update.  q and k are channel slices of the dw-conv output.  perm_out [G][C];
+// forced_perm (or null) overrides the computed order.  cache_in null = None.
+void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWeights& w,
+                           const float* cache_in, int cache_c, float* cache_out,
+                           const HintAttnScratch& sc, int* perm_out, const int* forced_perm,
+                           hipStream_t s);
+
+// ---- kernel accounting -----------------------------------------------------------------------
+struct KernelClock;
+KernelClock* current_clock();
+void set_current_clock(KernelClock* c);
+// RAII marker placed around a launch: records (name, flops, bytes) and, when a clock is
+// installed, brackets the launch with HIP events.
+struct Scope {
+  Scope(const char* name, double flops, double bytes, hipStream_t s);
+  ~Scope();
+  void* h;
+};
+
+}  // namespace jirf

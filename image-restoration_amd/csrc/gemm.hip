@@ -1,0 +1,363 @@
+// fp32 MFMA GEMM family of libjirf_hip (gfx950).
+//
+// One kernel template covers every dense contraction of the forward passes:
+//   * 1x1 convolutions / Conv1d(k=1) / Linear:      Y[o][p] = sum_k W[o][k] X[k][p]
+//   * attention * V with a gathered channel order (per-image "weight" = attention matrix)
+//   * dense 3x3 convolutions as an implicit GEMM over k = tap * Cin + c
+// Activations are planar ([channel][pixel], pixel contiguous), so the pixel axis sits on the
+// MFMA column (lane) index: loads and stores are 128-byte row segments.  Arithmetic is
+// v_mfma_f32_32x32x2_f32: exact fp32 fma chains, k-ordered.
+//
+// Tile: BM output channels x BN pixels per 256-thread workgroup (2 x 2 waves), K stepped by 16
+// through a double-buffered LDS image [k][m] / [k][n]; operands are staged through registers so
+// the loader can mask, gather, normalise (LayerNorm folded into the load) or shift (3x3 taps).
+#include "common.h"
+
+namespace jirf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float gelu_erf(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// Blocks b and b + 8 share an XCD (round-robin dispatch).  Remap so that consecutive logical
+// tiles — which share the same activation columns — land on one XCD's L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = id & 7, local = id >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}
+
+template <int BM, int BN, int LOADER, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a, const int tiles_m,
+                                                   const int tiles_n) {
+  constexpr int BK = GEMM_BK;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int XS = (BK * BN / 4 + 255) / 256;  // float4 slots per thread, activation tile
+  constexpr int WS = (BK * BM / 4 + 255) / 256;  // float4 slots per thread, weight tile
+  constexpr bool X_FULL = (BK * BN / 4) % 256 == 0;
+  constexpr bool W_FULL = (BK * BM / 4) % 256 == 0;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int per_img = tiles_m * tiles_n;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = id / per_img;
+  id -= b * per_img;
+  const int tile_n = id / tiles_m;
+  const int tile_m = id - tile_n * tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const float* __restrict__ wt = a.wt + (long)b * a.wt_bs;
+  const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
+  const int K = a.K, P = a.P;
+  const int nk = (K + BK - 1) / BK;
+
+  // ---- per-slot loader state ----------------------------------------------------------------
+  int x_row[XS], x_col[XS];
+  bool x_on[XS];
+#pragma unroll
+  for (int i = 0; i < XS; ++i) {
+    const int s = tid + i * 256;
+    x_row[i] = s / (BN / 4);
+    x_col[i] = (s - x_row[i] * (BN / 4)) * 4;
+    x_on[i] = X_FULL || s < BK * BN / 4;
+  }
+  float4 ln_mu[XS], ln_rs[XS];
+  int cv_yx[XS][4];
+  if constexpr (LOADER == LD_LN) {
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int p = n0 + x_col[i];
+      float mu[4], rs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = x_on[i] && p + j < P;
+        mu[j] = ok ? a.mu[(long)b * P + p + j] : 0.f;
+        rs[j] = ok ? a.rstd[(long)b * P + p + j] : 0.f;
+      }
+      ln_mu[i] = make_float4(mu[0], mu[1], mu[2], mu[3]);
+      ln_rs[i] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+    }
+  }
+  if constexpr (LOADER == LD_CONV3) {
+#pragma unroll
+    for (int i = 0; i < XS; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = n0 + x_col[i] + j;
+        const int yy = p / a.W;
+        cv_yx[i][j] = p < P ? ((yy << 16) | (p - yy * a.W)) : -1;
+      }
+  }
+  const int* __restrict__ kidx = nullptr;
+  if constexpr (LOADER == LD_GATHER) kidx = a.kidx + (long)(b / a.imgs_per_group) * K;
+
+  auto load_x = [&](int kt, int i) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int k = kt * BK + x_row[i];
+    if (!x_on[i] || k >= K) return v;
+    const int p = n0 + x_col[i];
+    if constexpr (LOADER == LD_CONV3) {
+      const int tap = k / a.Cin;
+      const int c = k - tap * a.Cin;
+      const int t3 = tap / 3;
+      const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+      const float* __restrict__ plane = xb + (long)c * P;
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int yx = cv_yx[i][j];
+        const int yy = (yx >> 16) + dy, xx = (yx & 0xffff) + dx;
+        const bool ok = yx >= 0 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        r[j] = ok ? plane[yy * a.W + xx] : 0.f;
+      }
+      return make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+      int row = k;
+      if constexpr (LOADER == LD_GATHER) row = kidx[k];
+      const float* __restrict__ src = xb + (long)row * P + p;
+      if constexpr (VEC) {
+        if (p < P) v = *reinterpret_cast<const float4*>(src);
+      } else {
+        if (p < P) v.x = src[0];
+        if (p + 1 < P) v.y = src[1];
+        if (p + 2 < P) v.z = src[2];
+        if (p + 3 < P) v.w = src[3];
+      }
+      if constexpr (LOADER == LD_LN) {
+        const float g = a.lnw[k];
+        const float be = a.lnb ? a.lnb[k] : 0.f;
+        const float4 mu = ln_mu[i], rs = ln_rs[i];
+        if (a.ln_center) {
+          v.x = (v.x - mu.x) * rs.x * g + be;
+          v.y = (v.y - mu.y) * rs.y * g + be;
+          v.z = (v.z - mu.z) * rs.z * g + be;
+          v.w = (v.w - mu.w) * rs.w * g + be;
+        } else {
+          v.x = v.x * rs.x * g;
+          v.y = v.y * rs.y * g;
+          v.z = v.z * rs.z * g;
+          v.w = v.w * rs.w * g;
+        }
+        // columns past the image must stay zero (rs == 0 there already zeroes the product,
+        // but the bias term would not)
+        if (p >= P) v.x = 0.f;
+        if (p + 1 >= P) v.y = 0.f;
+        if (p + 2 >= P) v.z = 0.f;
+        if (p + 3 >= P) v.w = 0.f;
+      }
+      return v;
+    }
+  };
+  auto load_w = [&](int kt, int i) -> float4 {
+    const int s = tid + i * 256;
+    if (!W_FULL && s >= BK * BM / 4) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int row = s / (BM / 4);
+    const int col = (s - row * (BM / 4)) * 4;
+    return *reinterpret_cast<const float4*>(wt + (long)(kt * BK + row) * a.Mpad + m0 + col);
+  };
+  auto store_tiles = [&](int buf, const float4* xr, const float4* wr) {
+#pragma unroll
+    for (int i = 0; i < XS; ++i)
+      if (x_on[i]) *reinterpret_cast<float4*>(&Bs[buf][x_row[i] * BN + x_col[i]]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WS; ++i) {
+      const int s = tid + i * 256;
+      if (W_FULL || s < BK * BM / 4) *reinterpret_cast<float4*>(&As[buf][s * 4]) = wr[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 xr[XS], wr[WS];
+#pragma unroll
+  for (int i = 0; i < XS; ++i) xr[i] = load_x(0, i);
+#pragma unroll
+  for (int i = 0; i < WS; ++i) wr[i] = load_w(0, i);
+  store_tiles(0, xr, wr);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < XS; ++i) xr[i] = load_x(kt + 1, i);
+#pragma unroll
+      for (int i = 0; i < WS; ++i) wr[i] = load_w(kt + 1, i);
+    }
+    const float* __restrict__ Ab = &As[buf][wm * WM + l31];
+    const float* __restrict__ Bb = &Bs[buf][wn * WN + l31];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bb[(kk + half) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1, xr, wr);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  const int M = a.M;
+  const int epi = a.epi;
+  float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WN + j * 32 + l31;
+    if (col >= P) continue;
+    int py = 0, px = 0;
+    if (epi == EP_UNSHUFFLE || epi == EP_SHUFFLE) {
+      py = col / a.W;
+      px = col - py * a.W;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row >= M) continue;
+        float v = acc[i][j][r];
+        if (a.bias) v += a.bias[row];
+        switch (epi) {
+          case EP_STORE:
+            yb[(long)row * P + col] = v;
+            break;
+          case EP_RESID:
+            yb[(long)row * P + col] = v + a.r.p[(long)b * a.r.bs + (long)row * P + col];
+            break;
+          case EP_GELU_MUL:
+            yb[(long)row * P + col] =
+                gelu_erf(v) * a.r.p[(long)b * a.r.bs + (long)row * P + col];
+            break;
+          case EP_AV_INTRA: {
+            const int src = a.kidx[(long)(b / a.imgs_per_group) * M + row];
+            const float qv = a.q.p[(long)b * a.q.bs + (long)src * P + col];
+            const float kv = a.k.p[(long)b * a.k.bs + (long)src * P + col];
+            yb[(long)row * P + col] = v;
+            a.y2.p[(long)b * a.y2.bs + (long)row * P + col] =
+                v + (qv * a.rq[(long)b * M + src] + kv * a.rk[(long)b * M + src]);
+            break;
+          }
+          case EP_UNSHUFFLE: {
+            const int oc = 4 * row + 2 * (py & 1) + (px & 1);
+            yb[(long)oc * (P >> 2) + (long)(py >> 1) * (a.W >> 1) + (px >> 1)] = v;
+            break;
+          }
+          case EP_SHUFFLE: {
+            const int oc = row >> 2;
+            const int oy = 2 * py + ((row >> 1) & 1), ox = 2 * px + (row & 1);
+            yb[(long)oc * (4L * P) + (long)oy * (2 * a.W) + ox] = v;
+            break;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static void launch_tile(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.P + BN - 1) / BN;
+  const dim3 grid((unsigned)(tiles_m * tiles_n * a.B)), block(256);
+#define JIRF_GEMM_CASE(LD, V) \
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, LD, V>), grid, block, 0, s, a, tiles_m, tiles_n)
+  switch (loader) {
+    case LD_PLAIN:
+      if (vec) JIRF_GEMM_CASE(LD_PLAIN, true); else JIRF_GEMM_CASE(LD_PLAIN, false);
+      break;
+    case LD_GATHER:
+      if (vec) JIRF_GEMM_CASE(LD_GATHER, true); else JIRF_GEMM_CASE(LD_GATHER, false);
+      break;
+    case LD_LN:
+      if (vec) JIRF_GEMM_CASE(LD_LN, true); else JIRF_GEMM_CASE(LD_LN, false);
+      break;
+    case LD_CONV3:
+      JIRF_GEMM_CASE(LD_CONV3, false);
+      break;
+    default:
+      JIRF_REQUIRE(false, JIRF_EINVAL, "launch_gemm: unknown loader %d", loader);
+  }
+#undef JIRF_GEMM_CASE
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gemm(const GemmArgs& a, int loader, hipStream_t s) {
+  JIRF_REQUIRE(a.B > 0 && a.M > 0 && a.K > 0 && a.P > 0, JIRF_EINVAL,
+               "launch_gemm: empty problem B=%d M=%d K=%d P=%d", a.B, a.M, a.K, a.P);
+  JIRF_REQUIRE(a.Mpad % GEMM_MPAD == 0 && a.Mpad >= a.M, JIRF_EINVAL,
+               "launch_gemm: packed row length %d does not cover M=%d", a.Mpad, a.M);
+  if (loader == LD_CONV3)
+    JIRF_REQUIRE(a.H * a.W == a.P && a.K == 9 * a.Cin && a.H < 65536 && a.W < 65536, JIRF_EINVAL,
+                 "launch_gemm: conv3x3 geometry H=%d W=%d P=%d K=%d Cin=%d", a.H, a.W, a.P, a.K,
+                 a.Cin);
+  if (a.epi == EP_UNSHUFFLE || a.epi == EP_SHUFFLE)
+    JIRF_REQUIRE(a.H * a.W == a.P && (a.epi == EP_SHUFFLE || (a.H % 2 == 0 && a.W % 2 == 0)),
+                 JIRF_EINVAL, "launch_gemm: (un)shuffle geometry H=%d W=%d P=%d", a.H, a.W, a.P);
+  // float4 activation loads need 16-byte aligned rows: pixel count and strides multiples of 4
+  const bool vec = a.P % 4 == 0 && a.x.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x.p) & 15) == 0;
+  const long b128 = (long)((a.M + 127) / 128) * ((a.P + 127) / 128) * a.B;
+  const long b64x128 = (long)((a.M + 63) / 64) * ((a.P + 127) / 128) * a.B;
+  const char* name = loader == LD_CONV3 ? "gemm_conv3x3" : loader == LD_GATHER ? "gemm_attn_v"
+                     : loader == LD_LN  ? "gemm_ln_1x1" : "gemm_1x1";
+  const double flops = 2.0 * a.M * (double)a.K * a.P * a.B;
+  const double kin = loader == LD_CONV3 ? a.Cin : a.K;
+  double bytes = 4.0 * a.B * (double)a.P * (kin + a.M) + 4.0 * a.K * (double)a.M * (a.wt_bs ? a.B : 1);
+  if (a.epi == EP_RESID || a.epi == EP_GELU_MUL) bytes += 4.0 * a.B * (double)a.P * a.M;
+  if (a.epi == EP_AV_INTRA) bytes += 4.0 * a.B * (double)a.P * a.M * 3;
+  Scope sc(name, flops, bytes, s);
+  if (a.M > 64 && b128 >= 512)
+    launch_tile<128, 128>(a, loader, vec, s);
+  else if (b64x128 >= 512)
+    launch_tile<64, 128>(a, loader, vec, s);
+  else
+    launch_tile<64, 64>(a, loader, vec, s);
+}
+
+int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad) {
+  const int mp = (M + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+  const int kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  out.assign((size_t)kp * mp, 0.f);
+  for (int o = 0; o < M; ++o)
+    for (int k = 0; k < K; ++k) out[(size_t)k * mp + o] = w[(size_t)o * K + k];
+  *Mpad = mp;
+  return kp;
+}
+
+// w [M][Cin][3][3] -> Wt[(tap * Cin + c)][o]
+int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad) {
+  const int K = 9 * Cin;
+  const int mp = (M + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+  const int kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  out.assign((size_t)kp * mp, 0.f);
+  for (int o = 0; o < M; ++o)
+    for (int c = 0; c < Cin; ++c)
+      for (int t = 0; t < 9; ++t)
+        out[(size_t)(t * Cin + c) * mp + o] = w[((size_t)o * Cin + c) * 9 + t];
+  *Mpad = mp;
+  return kp;
+}
+
+}  // namespace jirf

@@ -1,0 +1,679 @@
+// HINT channel attention (HMHA) statistics and C x C micro-kernels for gfx950.
+//
+// Reference semantics: Attention.execute / ReGroup / Inter_CacheModulation /
+// calculate_layer_cache / AdaptiveAvgPool2d in basicsr/models/archs/hint_arch.py:59-95,189-210,
+// 231-296,345-399.
+//
+// Pipeline per attention block (q, k are channel slices [C][P] of the depthwise-conv output):
+//   1. chan_stats   one pass over q and k: split-K contraction over the pixel axis producing
+//                   partial Q.K^T (fp32 MFMA), partial Q.Q^T and row sums (fp64 MFMA — these feed
+//                   an argsort, see below), partial sum q^2 / sum k^2.
+//   2. regroup_rows deterministic reduction of the partial slabs; row i of the channel
+//                   correlation matrix -> mean similarity; reciprocal L2 norms.
+//   3. group_attn   one workgroup per (channel group, image): ranks the similarities (the channel
+//                   permutation), gathers its c x c block of Q.K^T, scales by the norms and the
+//                   temperature, row softmax, inter-cache modulation, writes the block both in the
+//                   GEMM weight layout (for attention * V) and in natural orientation.
+//   4. cache_update bilinear upsample of every group's (batch-mean) attention to C x C, float
+//                   floor-division, momentum update of qv_cache.
+//
+// Why fp64 for Q.Q^T: the channel order is an argsort of the correlation row means, and adjacent
+// means are routinely 1e-7 apart at C = 384.  fp64 accumulation makes the computed means the
+// rounding-free value of the reference's formula, so ties are decided by the data, not by the
+// summation order.
+#include "common.h"
+
+namespace jirf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ST_T = 64;    // channel tile edge of the statistics kernel
+constexpr int ST_CH = 32;   // pixels per staged chunk
+constexpr int ST_LD = 33;   // LDS row stride (floats)
+constexpr float NORM_EPS = 1e-30f;
+
+__device__ __forceinline__ float gelu_erf_a(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. statistics
+// ------------------------------------------------------------------------------------------------
+struct StatsArgs {
+  const float* q; long q_bs;     // per-image q (Q.K^T rows, sum q^2)
+  const float* k; long k_bs;     // per-image k
+  const float* qg; long qg_bs;   // gram source: q of the image (per-image mode) or batch-mean q
+  int C, P, tiles, splits, chunks_per_split;
+  float* qk_part;    // [nb][splits][C][C]
+  double* gram_part; // [nb][splits][C][C]
+  double* qsum_part; // [nb][splits][C]
+  float* q2_part;    // [nb][splits][C]
+  float* k2_part;    // [nb][splits][C]
+};
+
+template <bool DO_QK, bool DO_GRAM>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
+  __shared__ float Qi[ST_T * ST_LD];
+  __shared__ float Kj[DO_QK ? ST_T * ST_LD : 1];
+  __shared__ float Gi[DO_GRAM ? ST_T * ST_LD : 1];
+  __shared__ float Gj[DO_GRAM ? ST_T * ST_LD : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, quad = lane >> 4;
+  const int ti = blockIdx.x / a.tiles, tj = blockIdx.x % a.tiles;
+  const int sp = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, P = a.P;
+  const int i0 = ti * ST_T, j0 = tj * ST_T;
+  const int c_begin = sp * a.chunks_per_split;
+  const int c_end = min(c_begin + a.chunks_per_split, (P + ST_CH - 1) / ST_CH);
+
+  const float* __restrict__ qb = a.q + (long)b * a.q_bs;
+  const float* __restrict__ kb = a.k + (long)b * a.k_bs;
+  const float* __restrict__ gb = a.qg + (long)b * a.qg_bs;
+
+  f32x16 s_acc;
+  f64x4 g_acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g_acc[t][u][r] = 0.0;
+  double row_sum = 0.0;  // threads 0..63: sum of gram-source row i0+tid
+  float row_sq = 0.f;    // threads 0..63: sum q^2 of row i0+tid ; threads 64..127: sum k^2 of row j0+tid-64
+
+  // staging: 64 rows x 32 px = 512 float4 slots, two per thread
+  auto stage = [&](float* dst, const float* __restrict__ src, int r0, int px0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int s = tid + it * 256;
+      const int r = s >> 3, c4 = (s & 7) * 4;
+      const int row = r0 + r, px = px0 + c4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (row < C) {
+        const float* __restrict__ ptr = src + (long)row * P + px;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (px + e < P) v[e] = ptr[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[r * ST_LD + c4 + e] = v[e];
+    }
+  };
+
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int px0 = ch * ST_CH;
+    if constexpr (DO_QK) {
+      stage(Qi, qb, i0, px0);
+      stage(Kj, kb, j0, px0);
+    }
+    if constexpr (DO_GRAM) {
+      stage(Gi, gb, i0, px0);
+      stage(Gj, gb, j0, px0);
+    }
+    __syncthreads();
+    if constexpr (DO_QK) {
+      if (i0 + wi * 32 < C && j0 + wj * 32 < C) {
+        const float* __restrict__ ap = &Qi[(wi * 32 + l31) * ST_LD + half];
+        const float* __restrict__ bp = &Kj[(wj * 32 + l31) * ST_LD + half];
+#pragma unroll
+        for (int s = 0; s < ST_CH / 2; ++s)
+          s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], s_acc, 0, 0, 0);
+      }
+      if (tj == 0 && tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < ST_CH; ++e) t = fmaf(Qi[tid * ST_LD + e], Qi[tid * ST_LD + e], t);
+        row_sq += t;
+      }
+      if (ti == 0 && tid >= 64 && tid < 128) {
+        const int r = tid - 64;
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < ST_CH; ++e) t = fmaf(Kj[r * ST_LD + e], Kj[r * ST_LD + e], t);
+        row_sq += t;
+      }
+    }
+    if constexpr (DO_GRAM) {
+      if (i0 + wi * 32 < C && j0 + wj * 32 < C) {
+#pragma unroll
+        for (int s = 0; s < ST_CH / 4; ++s) {
+          double av[2], bv[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            av[t] = (double)Gi[(wi * 32 + t * 16 + l15) * ST_LD + 4 * s + quad];
+            bv[t] = (double)Gj[(wj * 32 + t * 16 + l15) * ST_LD + 4 * s + quad];
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              g_acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[u], g_acc[t][u], 0, 0, 0);
+        }
+      }
+      if (tj == 0 && tid >= 128 && tid < 192) {
+        const int r = tid - 128;
+        double t = 0.0;
+#pragma unroll
+        for (int e = 0; e < ST_CH; ++e) t += (double)Gi[r * ST_LD + e];
+        row_sum += t;
+      }
+    }
+    __syncthreads();
+  }
+
+  const long slab = ((long)b * a.splits + sp) * C;
+  if constexpr (DO_QK) {
+    float* __restrict__ out = a.qk_part + slab * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int col = j0 + wj * 32 + l31;
+      if (row < C && col < C) out[(long)row * C + col] = s_acc[r];
+    }
+    if (tj == 0 && tid < 64 && i0 + tid < C) a.q2_part[slab + i0 + tid] = row_sq;
+    if (ti == 0 && tid >= 64 && tid < 128 && j0 + tid - 64 < C) a.k2_part[slab + j0 + tid - 64] = row_sq;
+  }
+  if constexpr (DO_GRAM) {
+    double* __restrict__ out = a.gram_part + slab * C;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + wi * 32 + t * 16 + quad + 4 * r;
+          const int col = j0 + wj * 32 + u * 16 + l15;
+          if (row < C && col < C) out[(long)row * C + col] = g_acc[t][u][r];
+        }
+    if (tj == 0 && tid >= 128 && tid < 192 && i0 + tid - 128 < C)
+      a.qsum_part[slab + i0 + tid - 128] = row_sum;
+  }
+}
+
+// batch mean of q for the coupled mode: qmean[c][p] = mean_b q[b][c][p]
+__global__ __launch_bounds__(256) void batch_mean_kernel(const float* __restrict__ q, long q_bs,
+                                                         float* __restrict__ out, int B, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += q[(long)b * q_bs + i];
+  out[i] = s / (float)B;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. slab reduction, correlation row means, reciprocal norms
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_double(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void regroup_rows_kernel(
+    const float* __restrict__ qk_part, const double* __restrict__ gram_part,
+    const double* __restrict__ qsum_part, const float* __restrict__ q2_part,
+    const float* __restrict__ k2_part, float* __restrict__ s_qk, float* __restrict__ rq,
+    float* __restrict__ rk, double* __restrict__ sim, int C, int P, int splits, int ipg) {
+  extern __shared__ double dsm[];  // mean[C], dstd[C], red[256]
+  double* mean = dsm;
+  double* dstd = dsm + C;
+  double* red = dsm + 2 * C;
+  const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+
+  for (int j = tid; j < C; j += 256) {
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += qk_part[(((long)b * splits + sp) * C + i) * C + j];
+    s_qk[((long)b * C + i) * C + j] = s;
+  }
+  if (tid == 0) {
+    float q2 = 0.f, k2 = 0.f;
+    for (int sp = 0; sp < splits; ++sp) {
+      q2 += q2_part[((long)b * splits + sp) * C + i];
+      k2 += k2_part[((long)b * splits + sp) * C + i];
+    }
+    rq[(long)b * C + i] = 1.0f / sqrtf(fmaxf(q2, NORM_EPS));
+    rk[(long)b * C + i] = 1.0f / sqrtf(fmaxf(k2, NORM_EPS));
+  }
+  if (b % ipg != 0) return;
+  const int g = b / ipg;
+  const double L = (double)P;
+  for (int j = tid; j < C; j += 256) {
+    double qs = 0.0, gjj = 0.0;
+    for (int sp = 0; sp < splits; ++sp) {
+      qs += qsum_part[((long)g * splits + sp) * C + j];
+      gjj += gram_part[(((long)g * splits + sp) * C + j) * C + j];
+    }
+    const double m = qs / L;
+    mean[j] = m;
+    dstd[j] = sqrt((gjj - L * m * m) / (L - 1.0));
+  }
+  __syncthreads();
+  double acc = 0.0;
+  const double mi = mean[i], di = dstd[i];
+  for (int j = tid; j < C; j += 256) {
+    double gij = 0.0;
+    for (int sp = 0; sp < splits; ++sp) gij += gram_part[(((long)g * splits + sp) * C + i) * C + j];
+    acc += ((gij - L * mi * mean[j]) / (L - 1.0)) / (di * dstd[j]);
+  }
+  const double tot = block_sum_double(acc, red);
+  if (tid == 0) sim[(long)g * C + i] = tot / (double)C;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 0. cache pooling  (AdaptiveAvgPool2d of the carried cache to this block's C)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pool_start(int i, int n_in, int n_out) { return (i * n_in) / n_out; }
+__device__ __forceinline__ int pool_end(int i, int n_in, int n_out) {
+  return ((i + 1) * n_in + n_out - 1) / n_out;
+}
+
+__global__ __launch_bounds__(256) void cache_pool_kernel(const float* __restrict__ in, int Cin,
+                                                         float* __restrict__ out, int C) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (idx >= C * C) return;
+  const int i = idx / C, j = idx - i * C;
+  const float* __restrict__ src = in + (long)g * Cin * Cin;
+  if (Cin == C) {
+    out[(long)g * C * C + idx] = src[idx];
+    return;
+  }
+  const int ys = pool_start(i, Cin, C), ye = pool_end(i, Cin, C);
+  const int xs = pool_start(j, Cin, C), xe = pool_end(j, Cin, C);
+  double s = 0.0;
+  for (int y = ys; y < ye; ++y)
+    for (int x = xs; x < xe; ++x) s += (double)src[(long)y * Cin + x];
+  out[(long)g * C * C + idx] = (float)(s / (double)((ye - ys) * (xe - xs)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. per-group attention
+// ------------------------------------------------------------------------------------------------
+struct GroupAttnArgs {
+  int C, G, ipg, Mpad;
+  int gsz[4], goff[4];
+  const double* sim;        // [G][C]
+  const int* forced_perm;   // [G][C] or null
+  int* perm_out;            // [G][C]
+  const float* s_qk;        // [B][C][C]
+  const float* rq;          // [B][C]
+  const float* rk;          // [B][C]
+  const float* temperature; // [4]
+  const float* pooled;      // [G][C][C] or null (no cache)
+  const float* cw_w[4];
+  const float* cw_b[4];
+  const float* gc_w[4];
+  const float* gc_b[4];
+  float* att_t;             // [B][Kpad][Mpad]
+  float* att_nat;           // [B][C][C]
+};
+
+constexpr int GA_JC = 32;  // columns modulated per pass
+
+__device__ __forceinline__ double sort_key(double v) { return v != v ? -INFINITY : v; }
+
+__global__ __launch_bounds__(256) void group_attn_kernel(const GroupAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ga_smem[];
+  const int gi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int C = a.C, c = a.gsz[gi], off = a.goff[gi];
+  const int g = b / a.ipg;
+  const int ld = c + 1;
+  double* key = reinterpret_cast<double*>(ga_smem);            // [C]
+  int* perm = reinterpret_cast<int*>(key + C);                 // [C]
+  float* X = reinterpret_cast<float*>(perm + C + (C & 1));     // [c][ld]
+  float* XP = X + c * ld;                                      // [c][JC]
+  float* Y = XP + c * GA_JC;                                   // [c][JC]
+
+  // ---- channel permutation: descending similarity, ties by ascending channel ----
+  if (a.forced_perm) {
+    for (int i = tid; i < C; i += 256) perm[i] = a.forced_perm[(long)g * C + i];
+  } else {
+    for (int i = tid; i < C; i += 256) key[i] = sort_key(a.sim[(long)g * C + i]);
+    __syncthreads();
+    for (int i = tid; i < C; i += 256) {
+      const double ki = key[i];
+      int rank = 0;
+      for (int j = 0; j < C; ++j) {
+        const double kj = key[j];
+        rank += (kj > ki) || (kj == ki && j < i);
+      }
+      perm[rank] = i;
+    }
+  }
+  __syncthreads();
+  if (gi == 0 && b % a.ipg == 0)
+    for (int i = tid; i < C; i += 256) a.perm_out[(long)g * C + i] = perm[i];
+
+  // ---- gather + scale: X[r][s] = S[perm r][perm s] * rq[perm r] * rk[perm s] * T ----
+  const float temp = a.temperature[gi];
+  const float* __restrict__ S = a.s_qk + (long)b * C * C;
+  for (int e = tid; e < c * c; e += 256) {
+    const int r = e / c, s = e - r * c;
+    const int ci = perm[off + r], cj = perm[off + s];
+    X[r * ld + s] = S[(long)ci * C + cj] * a.rq[(long)b * C + ci] * a.rk[(long)b * C + cj] * temp;
+  }
+  __syncthreads();
+  // ---- row softmax (one wave per row) ----
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < c; r += 4) {
+      float m = -INFINITY;
+      for (int s = lane; s < c; s += 64) m = fmaxf(m, X[r * ld + s]);
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float sum = 0.f;
+      for (int s = lane; s < c; s += 64) {
+        const float e = expf(X[r * ld + s] - m);
+        X[r * ld + s] = e;
+        sum += e;
+      }
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float inv = 1.0f / sum;
+      for (int s = lane; s < c; s += 64) X[r * ld + s] *= inv;
+    }
+  }
+  __syncthreads();
+
+  float* __restrict__ att_t = a.att_t + (long)b * (((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD) * a.Mpad;
+  float* __restrict__ att_nat = a.att_nat + (long)b * C * C;
+
+  // Rows [off, off + c) of the transposed image belong to this group (the last group also owns
+  // the padding rows); everything outside the diagonal block must read as zero in the GEMM.
+  {
+    const int kpad = ((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD;
+    const int row_end = gi == 3 ? kpad : off + c;
+    for (int e = tid; e < (row_end - off) * a.Mpad; e += 256) {
+      const int kr = off + e / a.Mpad, m = e % a.Mpad;
+      if (kr >= off + c || m < off || m >= off + c) att_t[(long)kr * a.Mpad + m] = 0.f;
+    }
+  }
+
+  if (!a.pooled) {
+    for (int e = tid; e < c * c; e += 256) {
+      const int r = e / c, s = e - r * c;
+      const float v = X[r * ld + s];
+      att_nat[(long)(off + r) * C + off + s] = v;
+    }
+    for (int e = tid; e < c * c; e += 256) {  // transposed store, m (row) fastest
+      const int s = e / c, r = e - s * c;
+      att_t[(long)(off + s) * a.Mpad + off + r] = X[r * ld + s];
+    }
+    return;
+  }
+
+  // ---- inter-cache modulation, JC columns at a time (Conv1d(k=1) mixes rows, so columns are
+  //      independent):  Z = Ww (pool(cache) + X) + bw ; Y = X * Z[:c] + Z[c:] ;
+  //      att = Y * gelu(Wg Y + bg) + X ----
+  const float* __restrict__ pooled = a.pooled + (long)g * C * C;
+  const float* __restrict__ Ww = a.cw_w[gi];
+  const float* __restrict__ bw = a.cw_b[gi];
+  const float* __restrict__ Wg = a.gc_w[gi];
+  const float* __restrict__ bg = a.gc_b[gi];
+  for (int jc = 0; jc < c; jc += GA_JC) {
+    const int nj = min(GA_JC, c - jc);
+    // pooled cache (C x C -> c x c) + X
+    for (int e = tid; e < c * GA_JC; e += 256) {
+      const int r = e / GA_JC, jj = e - r * GA_JC;
+      float v = 0.f;
+      if (jj < nj) {
+        const int s = jc + jj;
+        const int ys = pool_start(r, C, c), ye = pool_end(r, C, c);
+        const int xs = pool_start(s, C, c), xe = pool_end(s, C, c);
+        double acc = 0.0;
+        for (int y = ys; y < ye; ++y)
+          for (int x = xs; x < xe; ++x) acc += (double)pooled[(long)y * C + x];
+        v = (float)(acc / (double)((ye - ys) * (xe - xs))) + X[r * ld + s];
+      }
+      XP[r * GA_JC + jj] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < c * GA_JC; e += 256) {
+      const int o = e / GA_JC, jj = e - o * GA_JC;
+      float sc = bw[o], sh = bw[c + o];
+      const float* __restrict__ w0 = Ww + (long)o * c;
+      const float* __restrict__ w1 = Ww + (long)(c + o) * c;
+      for (int i = 0; i < c; ++i) {
+        const float xv = XP[i * GA_JC + jj];
+        sc = fmaf(w0[i], xv, sc);
+        sh = fmaf(w1[i], xv, sh);
+      }
+      Y[o * GA_JC + jj] = jj < nj ? X[o * ld + jc + jj] * sc + sh : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < c * GA_JC; e += 256) {
+      const int o = e / GA_JC, jj = e - o * GA_JC;
+      if (jj >= nj) continue;
+      float gt = bg[o];
+      const float* __restrict__ w0 = Wg + (long)o * c;
+      for (int i = 0; i < c; ++i) gt = fmaf(w0[i], Y[i * GA_JC + jj], gt);
+      const int s = jc + jj;
+      const float v = Y[o * GA_JC + jj] * gelu_erf_a(gt) + X[o * ld + s];
+      att_nat[(long)(off + o) * C + off + s] = v;
+      att_t[(long)(off + s) * a.Mpad + off + o] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. layer cache + momentum update
+// ------------------------------------------------------------------------------------------------
+struct CacheUpdArgs {
+  int C, ipg;
+  int gsz[4], goff[4];
+  const float* att_nat;  // [B][C][C]
+  const float* pooled;   // [G][C][C] or null
+  float* cache_out;      // [G][C][C]
+};
+
+__global__ __launch_bounds__(256) void cache_update_kernel(const CacheUpdArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  const int C = a.C;
+  if (idx >= C * C) return;
+  const int oy = idx / C, ox = idx - oy * C;
+  float total = 0.f;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int c = a.gsz[gi], off = a.goff[gi];
+    // bilinear, align_corners = False: src = scale * (dst + 0.5) - 0.5 clamped at 0
+    const float scale = (float)c / (float)C;
+    float sy = scale * ((float)oy + 0.5f) - 0.5f;
+    float sx = scale * ((float)ox + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = min(y0, c - 1);
+    x0 = min(x0, c - 1);
+    const int y1 = min(y0 + 1, c - 1), x1 = min(x0 + 1, c - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+    for (int m = 0; m < a.ipg; ++m) {
+      const float* __restrict__ A = a.att_nat + ((long)(g * a.ipg + m) * C + off) * C + off;
+      v00 += A[(long)y0 * C + x0];
+      v01 += A[(long)y0 * C + x1];
+      v10 += A[(long)y1 * C + x0];
+      v11 += A[(long)y1 * C + x1];
+    }
+    if (a.ipg > 1) {
+      const float inv = (float)a.ipg;
+      v00 /= inv; v01 /= inv; v10 /= inv; v11 /= inv;
+    }
+    const float up = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    total += floorf((up * (float)c) / (float)C);
+  }
+  float outv;
+  if (a.pooled)
+    outv = a.pooled[(long)g * C * C + idx] * 0.9f + total * 0.1f;
+  else
+    outv = total * 0.9f;
+  a.cache_out[(long)g * C * C + idx] = outv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode) {
+  HintAttnShape sh{};
+  sh.B = B; sh.C = C; sh.P = P;
+  sh.G = batch_mode == JIRF_BATCH_COUPLED ? 1 : B;
+  const int ratio[4] = {1, 2, 2, 3};
+  int off = 0;
+  for (int i = 0; i < 4; ++i) {
+    // int(ratio / 8 * C) evaluated like the reference: double arithmetic, truncation
+    sh.gsz[i] = (int)((double)ratio[i] / 8.0 * (double)C);
+    sh.goff[i] = off;
+    off += sh.gsz[i];
+  }
+  const int tiles = (C + ST_T - 1) / ST_T;
+  const int chunks = (P + ST_CH - 1) / ST_CH;
+  // enough workgroups to fill the chip, but at least 8 chunks (256 px) per split
+  int want = (1024 + tiles * tiles * B - 1) / (tiles * tiles * B);
+  int splits = std::max(1, std::min(want, chunks / 8));
+  splits = std::min(splits, 64);
+  sh.splits = splits;
+  return sh;
+}
+
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+size_t hint_attn_scratch_carve(const HintAttnShape& sh, void* base, HintAttnScratch* o) {
+  size_t off = 0;
+  const size_t C = sh.C, B = sh.B, G = sh.G, S = sh.splits;
+  auto take = [&](size_t bytes) {
+    void* p = base ? static_cast<unsigned char*>(base) + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  const size_t kpad = (C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  const size_t mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+  o->gram_part = static_cast<double*>(take(G * S * C * C * 8));
+  o->qk_part = static_cast<float*>(take(B * S * C * C * 4));
+  o->qsum_part = static_cast<double*>(take(G * S * C * 8));
+  o->q2_part = static_cast<float*>(take(B * S * C * 4));
+  o->k2_part = static_cast<float*>(take(B * S * C * 4));
+  o->qmean = static_cast<float*>(take(G == B ? 0 : C * (size_t)sh.P * 4));
+  o->sim = static_cast<double*>(take(G * C * 8));
+  o->s_qk = static_cast<float*>(take(B * C * C * 4));
+  o->rq = static_cast<float*>(take(B * C * 4));
+  o->rk = static_cast<float*>(take(B * C * 4));
+  o->att_t = static_cast<float*>(take(B * kpad * mpad * 4));
+  o->att_nat = static_cast<float*>(take(B * C * C * 4));
+  o->pooled = static_cast<float*>(take(G * C * C * 4));
+  return off;
+}
+
+void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWeights& w,
+                           const float* cache_in, int cache_c, float* cache_out,
+                           const HintAttnScratch& sc, int* perm_out, const int* forced_perm,
+                           hipStream_t s) {
+  const int B = sh.B, C = sh.C, P = sh.P, G = sh.G, ipg = B / G;
+  JIRF_REQUIRE(sh.gsz[0] > 0 && sh.goff[3] + sh.gsz[3] <= C, JIRF_EINVAL,
+               "hint attention: channel count %d too small for 4 groups", C);
+  JIRF_REQUIRE(P >= 2, JIRF_EINVAL, "hint attention: needs at least 2 pixels");
+  const int tiles = (C + ST_T - 1) / ST_T;
+  const int chunks = (P + ST_CH - 1) / ST_CH;
+  const int cps = (chunks + sh.splits - 1) / sh.splits;
+  float* q2_part = sc.q2_part;
+  float* k2_part = sc.k2_part;
+  double* sim = sc.sim;
+
+  StatsArgs st{};
+  st.q = q.p; st.q_bs = q.bs; st.k = k.p; st.k_bs = k.bs;
+  st.C = C; st.P = P; st.tiles = tiles; st.splits = sh.splits; st.chunks_per_split = cps;
+  st.qk_part = sc.qk_part; st.gram_part = sc.gram_part; st.qsum_part = sc.qsum_part;
+  st.q2_part = q2_part; st.k2_part = k2_part;
+  const double tile_px = (double)tiles * tiles * ST_T * ST_T * (double)P;
+  if (ipg == 1) {
+    st.qg = q.p; st.qg_bs = q.bs;
+    Scope scope("hint_chan_stats", 4.0 * tile_px * B, 8.0 * B * (double)C * P, s);
+    hipLaunchKernelGGL((chan_stats_kernel<true, true>), dim3(tiles * tiles, sh.splits, B), dim3(256),
+                       0, s, st);
+  } else {
+    {
+      Scope scope("hint_batch_mean", (double)B * C * P, 4.0 * (B + 1) * (double)C * P, s);
+      const long n = (long)C * P;
+      hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q.p,
+                         q.bs, sc.qmean, B, n);
+    }
+    {
+      Scope scope("hint_chan_stats", 2.0 * tile_px * B, 8.0 * B * (double)C * P, s);
+      hipLaunchKernelGGL((chan_stats_kernel<true, false>), dim3(tiles * tiles, sh.splits, B),
+                         dim3(256), 0, s, st);
+    }
+    st.qg = sc.qmean; st.qg_bs = 0;
+    Scope scope("hint_chan_stats", 2.0 * tile_px, 4.0 * (double)C * P, s);
+    hipLaunchKernelGGL((chan_stats_kernel<false, true>), dim3(tiles * tiles, sh.splits, 1), dim3(256),
+                       0, s, st);
+  }
+  JIRF_HIP_CHECK(hipGetLastError());
+  {
+    Scope scope("hint_regroup_rows", 3.0 * C * (double)C * sh.splits * B,
+                (double)C * C * sh.splits * (4.0 * B + 8.0 * G), s);
+    const size_t smem = (2 * (size_t)C + 256) * sizeof(double);
+    hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), smem, s, sc.qk_part, sc.gram_part,
+                       sc.qsum_part, q2_part, k2_part, sc.s_qk, sc.rq, sc.rk, sim, C, P, sh.splits,
+                       ipg);
+    JIRF_HIP_CHECK(hipGetLastError());
+  }
+  const float* pooled = nullptr;
+  if (cache_in) {
+    Scope scope("hint_cache_pool", 0.0, 4.0 * G * ((double)cache_c * cache_c + (double)C * C), s);
+    hipLaunchKernelGGL(cache_pool_kernel, dim3((C * C + 255) / 256, G), dim3(256), 0, s, cache_in,
+                       cache_c, sc.pooled, C);
+    JIRF_HIP_CHECK(hipGetLastError());
+    pooled = sc.pooled;
+  }
+  {
+    GroupAttnArgs ga{};
+    ga.C = C; ga.G = G; ga.ipg = ipg;
+    ga.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+    int cmax = 0;
+    for (int i = 0; i < 4; ++i) {
+      ga.gsz[i] = sh.gsz[i]; ga.goff[i] = sh.goff[i];
+      ga.cw_w[i] = w.cw_w[i]; ga.cw_b[i] = w.cw_b[i]; ga.gc_w[i] = w.gc_w[i]; ga.gc_b[i] = w.gc_b[i];
+      cmax = std::max(cmax, sh.gsz[i]);
+    }
+    ga.sim = sim; ga.forced_perm = forced_perm; ga.perm_out = perm_out;
+    ga.s_qk = sc.s_qk; ga.rq = sc.rq; ga.rk = sc.rk; ga.temperature = w.temperature;
+    ga.pooled = pooled; ga.att_t = sc.att_t; ga.att_nat = sc.att_nat;
+    const size_t smem = (size_t)C * 8 + ((size_t)C + (C & 1)) * 4 +
+                        ((size_t)cmax * (cmax + 1) + 2 * (size_t)cmax * GA_JC) * 4;
+    JIRF_REQUIRE(smem <= 160 * 1024, JIRF_EINVAL,
+                 "hint attention: channel group of %d does not fit LDS (%zu bytes)", cmax, smem);
+    static bool attr_set = false;
+    if (!attr_set) {
+      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_attn_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    double fl = 0.0;
+    for (int i = 0; i < 4; ++i) fl += (pooled ? 6.0 : 0.0) * sh.gsz[i] * (double)sh.gsz[i] * sh.gsz[i];
+    Scope scope("hint_group_attn", fl * B, 12.0 * B * (double)C * C, s);
+    hipLaunchKernelGGL(group_attn_kernel, dim3(4, B), dim3(256), smem, s, ga);
+    JIRF_HIP_CHECK(hipGetLastError());
+  }
+  {
+    CacheUpdArgs cu{};
+    cu.C = C; cu.ipg = ipg;
+    for (int i = 0; i < 4; ++i) { cu.gsz[i] = sh.gsz[i]; cu.goff[i] = sh.goff[i]; }
+    cu.att_nat = sc.att_nat; cu.pooled = pooled; cu.cache_out = cache_out;
+    Scope scope("hint_cache_update", 40.0 * G * (double)C * C, 12.0 * G * (double)C * C, s);
+    hipLaunchKernelGGL(cache_update_kernel, dim3((C * C + 255) / 256, G), dim3(256), 0, s, cu);
+    JIRF_HIP_CHECK(hipGetLastError());
+  }
+}
+
+}  // namespace jirf

@@ -1,0 +1,178 @@
+// HBM-bound kernels of libjirf_hip (gfx950): channel LayerNorm, its statistics-only form, and the
+// depthwise 3x3 convolution with the GDFN gate fused in.
+//
+// Activations are planar [channel][pixel]; a wave's 64 lanes always sit on 64 (or 256) adjacent
+// pixels, so every global access is a full 256-B / 1-KiB row segment.
+#include "common.h"
+
+namespace jirf {
+
+__device__ __forceinline__ float gelu_erf_pw(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// ---- per-pixel LayerNorm over channels ---------------------------------------------------------
+// One lane per pixel.  Pass 1 sums the channels, pass 2 sums squared deviations (the two-pass
+// population variance the reference's `var(unbiased=False)` denotes), pass 3 writes; passes 2/3
+// re-read lines that pass 1 left in L2.
+// kind: 1 = WithBias ((x - mu) * rstd * w + b), 2 = BiasFree (x * rstd * w), 0 = statistics only.
+template <int KIND>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long x_bs,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y, long y_bs,
+                                                        float* __restrict__ mu_out,
+                                                        float* __restrict__ rstd_out, int C, int P) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= P) return;
+  const float* __restrict__ xp = x + (long)b * x_bs + p;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xp[(long)c * P];
+  const float mu = s / (float)C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = xp[(long)c * P] - mu;
+    v = fmaf(d, d, v);
+  }
+  const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+  if constexpr (KIND == 0) {
+    mu_out[(long)b * P + p] = mu;
+    rstd_out[(long)b * P + p] = rstd;
+  } else {
+    float* __restrict__ yp = y + (long)b * y_bs + p;
+    for (int c = 0; c < C; ++c) {
+      const float xv = xp[(long)c * P];
+      if constexpr (KIND == 1)
+        yp[(long)c * P] = (xv - mu) * rstd * w[c] + bias[c];
+      else
+        yp[(long)c * P] = xv * rstd * w[c];
+    }
+  }
+}
+
+void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
+                      hipStream_t s) {
+  JIRF_REQUIRE(kind == 1 || kind == 2, JIRF_EINVAL, "layernorm: kind %d", kind);
+  JIRF_REQUIRE(kind == 2 || b != nullptr, JIRF_EINVAL, "layernorm: WithBias needs a bias");
+  const dim3 grid((P + 255) / 256, B), block(256);
+  Scope sc("layernorm", 8.0 * B * (double)C * P, 8.0 * B * (double)C * P, s);
+  if (kind == 1)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, nullptr,
+                       nullptr, C, P);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, nullptr,
+                       nullptr, C, P);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s) {
+  const dim3 grid((P + 255) / 256, B), block(256);
+  Scope sc("ln_stats", 5.0 * B * (double)C * P, 4.0 * B * (double)P * (C + 2), s);
+  hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x.p, x.bs, nullptr, nullptr, nullptr,
+                     0L, mu, rstd, C, P);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+// ---- depthwise 3x3, zero padding 1 ---------------------------------------------------------------
+// A workgroup owns a TH x TW output tile of one channel plane (two planes when the gate is
+// fused), staged with its one-pixel halo in LDS; each lane then produces 4 adjacent pixels of a
+// row from 3 x 6 LDS values.  GATE: out[c] = gelu(dw(x[c])) * dw(x[c + Ch]) for c < Ch.
+constexpr int DW_TH = 16, DW_TW = 64;
+
+template <bool GATE>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, long x_bs,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y, long y_bs, int C,
+                                                        int H, int W, int tiles_x, int tiles_y) {
+  constexpr int LW = DW_TW + 2 + 2;  // halo + pad so rows are 68 floats (odd multiple of 4 banks)
+  __shared__ float tile[GATE ? 2 : 1][(DW_TH + 2) * LW];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int c = t / tiles_y;  // output channel
+  const int b = blockIdx.y;
+  const int x0 = tx * DW_TW, y0 = ty * DW_TH;
+  const long P = (long)H * W;
+  const int Cout = GATE ? C / 2 : C;
+
+#pragma unroll
+  for (int g = 0; g < (GATE ? 2 : 1); ++g) {
+    const float* __restrict__ plane = x + (long)b * x_bs + (long)(c + g * Cout) * P;
+    for (int i = tid; i < (DW_TH + 2) * (DW_TW + 2); i += 256) {
+      const int r = i / (DW_TW + 2), q = i - r * (DW_TW + 2);
+      const int yy = y0 + r - 1, xx = x0 + q - 1;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      tile[g][r * LW + q] = ok ? plane[(long)yy * W + xx] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int r = tid >> 4;          // 0..15 output row in tile
+  const int q = (tid & 15) * 4;    // 0..60 output col in tile
+  const int oy = y0 + r, ox = x0 + q;
+  if (oy >= H || ox >= W) return;
+  float res[GATE ? 2 : 1][4];
+#pragma unroll
+  for (int g = 0; g < (GATE ? 2 : 1); ++g) {
+    const int ch = c + g * Cout;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[ch * 9 + i];
+    const float bb = bias ? bias[ch] : 0.f;
+    float acc[4] = {bb, bb, bb, bb};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      float v[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = tile[g][(r + dy) * LW + q + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = fmaf(k[dy * 3 + 0], v[j], acc[j]);
+        acc[j] = fmaf(k[dy * 3 + 1], v[j + 1], acc[j]);
+        acc[j] = fmaf(k[dy * 3 + 2], v[j + 2], acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) res[g][j] = acc[j];
+  }
+  float out[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if constexpr (GATE)
+      out[j] = gelu_erf_pw(res[0][j]) * res[GATE ? 1 : 0][j];
+    else
+      out[j] = res[0][j];
+  }
+  float* __restrict__ dst = y + (long)b * y_bs + (long)c * P + (long)oy * W + ox;
+  if (ox + 3 < W && (W & 3) == 0 && (y_bs & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ox + j < W) dst[j] = out[j];
+  }
+}
+
+void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
+                      int gate, hipStream_t s) {
+  JIRF_REQUIRE(!gate || C % 2 == 0, JIRF_EINVAL, "dwconv3x3: gated form needs an even channel count");
+  const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
+  const int Cout = gate ? C / 2 : C;
+  const dim3 grid((unsigned)(tiles_x * tiles_y * Cout), B), block(256);
+  const double px = (double)B * H * W;
+  Scope sc(gate ? "dwconv3x3_gate" : "dwconv3x3", 18.0 * px * C, 4.0 * px * (C + Cout), s);
+  if (gate)
+    hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C,
+                       H, W, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL(dwconv3x3_kernel<false>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C,
+                       H, W, tiles_x, tiles_y);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace jirf

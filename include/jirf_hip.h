@@ -1,0 +1,168 @@
+/*
+ * libjirf_hip.so — C ABI of the MI355X (gfx950) inference forward of the JIRF
+ * restoration networks (HINT, ASTv2, AST).
+ *
+ * The reference has no FFI: the seam this library replaces is the Python class
+ * contract of `network_g` (reference basicsr/models/archs/__init__.py:44-47
+ * `define_network`, called from basicsr/models/image_restoration_model.py:141
+ * and from every <Task>/test_*.py, e.g. Deraining/test_rain100L.py:117-155):
+ * construct from the YAML kwargs, load a dict of arrays, call on an NCHW fp32
+ * tensor.  Each entry point below names the reference lines it stands in for.
+ *
+ * Conventions: plain pointers and sizes only.  Every function returns 0 on
+ * success or a negative JIRF_E* code; the message of the last failure on the
+ * calling thread is returned by jirf_last_error().  Nothing throws across the
+ * ABI.  A jirf_net is bound to one GPU and is not thread-safe: use one net per
+ * GPU per host thread/process.  Device pointers are fp32, NCHW, contiguous.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef JIRF_HIP_H
+#define JIRF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JIRF_ABI_VERSION 1
+
+#define JIRF_OK 0
+#define JIRF_EINVAL (-1)     /* bad argument / shape the network cannot take */
+#define JIRF_ENOTFOUND (-2)  /* unknown arch or parameter key */
+#define JIRF_ESTATE (-3)     /* call order violated (e.g. forward before finalize) */
+#define JIRF_EHIP (-4)       /* a HIP runtime call failed */
+#define JIRF_ENOMEM (-5)     /* device allocation failed */
+#define JIRF_ENOGPU (-6)     /* no usable gfx950 device */
+
+typedef struct jirf_net jirf_net;
+
+/* dtype tags of jirf_net_set_param */
+#define JIRF_F32 0
+#define JIRF_I32 1
+#define JIRF_I64 2
+#define JIRF_F64 3
+
+/* batch semantics of jirf_net_forward for B > 1 */
+#define JIRF_BATCH_PER_IMAGE 0 /* equals B separate B=1 reference calls (what every test script does) */
+#define JIRF_BATCH_COUPLED 1   /* the reference's literal B>1 call: HINT's regroup statistics and
+                                  cache use batch means (hint_arch.py:245,282) */
+
+int jirf_abi_version(void);
+int jirf_device_count(void);
+const char* jirf_last_error(void);
+
+/* ---- network objects ------------------------------------------------------------------- */
+
+/* Stands in for `cls(**opt)` of define_network (archs/__init__.py:22-47) with
+ * arch in {"HINT"} (ctor kwargs of hint_arch.py:495-508) — "ASTv2"
+ * (astv2_arch.py:303-315) and "AST" (ast_arch.py:941-965) are accepted once
+ * their kernels are built.  cfg_json is the `network_g` YAML block without
+ * `type`, as JSON.  Unknown arch: NULL + JIRF_ENOTFOUND. */
+jirf_net* jirf_net_create(const char* arch, const char* cfg_json, int device);
+void jirf_net_destroy(jirf_net* net);
+
+/* Stands in for one entry of `net.load_state_dict(checkpoint["params"])`
+ * (Deraining/test_rain100L.py:119-124; loader semantics basicsr/models/base_model.py:228-258).
+ * `key` is the reference's state-dict key; `host_data` is a host array of
+ * `dtype` with `shape[ndim]`, copied (the caller keeps ownership).  Keys the
+ * network does not own return JIRF_ENOTFOUND; a shape mismatch JIRF_EINVAL.
+ * `qv_cache` is accepted and ignored, as every test script deletes it. */
+int jirf_net_set_param(jirf_net* net, const char* key, const void* host_data, int dtype,
+                       const int64_t* shape, int ndim);
+
+/* Number of parameter keys the network expects and the i-th key/shape (for
+ * state_dict() and strict-load checks).  shape_out holds up to 4 dims. */
+int jirf_net_param_count(const jirf_net* net);
+int jirf_net_param_info(const jirf_net* net, int index, const char** key_out, int64_t* shape_out,
+                        int* ndim_out);
+/* Copy a parameter back to the host in its reference layout (fp32). */
+int jirf_net_get_param(const jirf_net* net, const char* key, float* host_out, size_t n_floats);
+
+/* Checks that every parameter was set, packs the weights into the kernels'
+ * layouts and uploads them.  Stands in for `.cuda(); .eval()` (test_rain100L.py:126-127). */
+int jirf_net_finalize(jirf_net* net);
+
+/* Sizes the activation arena for inputs of [B,3,H,W] (allocates device memory
+ * on first use or growth; forward never allocates afterwards).  Returns the
+ * arena size. */
+int jirf_net_plan(jirf_net* net, int B, int H, int W, int batch_mode, size_t* workspace_bytes);
+
+/* Stands in for `restored = model_restoration(input_)` (test_rain100L.py:155;
+ * HINT.execute hint_arch.py:657-706).  x, y: [B,3,H,W] fp32.  With
+ * on_device != 0 both are device pointers and the call is asynchronous on
+ * `stream`; otherwise they are host pointers and the call copies in, runs and
+ * copies out synchronously.  HINT carries `qv_cache` from call to call like
+ * the reference module attribute (hint_arch.py:511,660-696); see
+ * jirf_net_reset_cache. */
+int jirf_net_forward(jirf_net* net, const float* x, float* y, int B, int H, int W, int batch_mode,
+                     int on_device, void* stream);
+
+/* HINT's module attribute `self.qv_cache` (hint_arch.py:511): reset = None
+ * (cold start, what a freshly constructed model has); get/set copy one
+ * [n,C,C] host array (n = 1, or B in per-image mode).  get returns
+ * JIRF_ESTATE when the cache is None. */
+int jirf_net_reset_cache(jirf_net* net);
+int jirf_net_get_cache(jirf_net* net, float* host_out, int* n_out, int* c_out, size_t capacity_floats);
+int jirf_net_set_cache(jirf_net* net, const float* host_in, int n, int c);
+
+/* Diagnostics with no counterpart in the reference.  The channel order that
+ * ReGroup (hint_arch.py:241-253) derives from an argsort is discontinuous in
+ * its input, so two fp32 implementations can legitimately disagree on a near
+ * tie; these calls let a checker read the orders the last forward used
+ * ([n_attention_blocks][n_groups][C_of_block], int32, block order = execution
+ * order) and pin them for the next forwards (NULL clears the pin). */
+int jirf_net_attention_blocks(const jirf_net* net, int* n_blocks, int* channels_out, int capacity);
+int jirf_net_get_perms(jirf_net* net, int32_t* host_out, size_t capacity_ints, size_t* n_ints);
+int jirf_net_set_forced_perms(jirf_net* net, const int32_t* host_in, size_t n_ints);
+
+/* Per-kernel device time of the last forward, measured with HIP events around
+ * every launch when enabled (serialises the stream; off by default).
+ * names_out receives pointers to static strings. */
+int jirf_net_enable_kernel_timing(jirf_net* net, int enable);
+int jirf_net_kernel_times(jirf_net* net, const char** names_out, float* ms_out, double* flops_out,
+                          double* bytes_out, int* launches_out, int capacity, int* n_out);
+
+/* ---- single-kernel entry points (raw device pointers; used by the known-answer tests and by
+ *      rocprofv3 runs).  All tensors fp32 NCHW contiguous unless stated. ---------------------- */
+
+/* y[b,o,p] = sum_i w[o,i] x[b,i,p] (+bias[o]) (+res[b,o,p]) — nn.Conv2d(k=1)
+ * (hint_arch.py:156-161,173-178,306,316).  w_host [Cout,Cin], bias_host [Cout] or NULL are HOST
+ * arrays (packed and uploaded inside the call); res may be NULL. */
+int jirf_op_conv1x1(const float* x, const float* w_host, const float* bias_host, const float* res,
+                    float* y, int B, int Cin, int Cout, int P, void* stream);
+/* Same with LayerNorm folded in: y = W * LN(x) using per-pixel mean/rstd computed inside the
+ * call.  ln_kind 1 = WithBias, 2 = BiasFree (hint_arch.py:98-145). */
+int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
+                       const float* w_host, float* y, int B, int Cin, int Cout, int P, void* stream);
+/* Dense 3x3, stride 1, zero pad 1 (hint_arch.py:441-448,459-466,479-486,648-655).
+ * w_host [Cout,Cin,3,3].  mode 0: plain; 1: followed by pixel-unshuffle(2)
+ * (hint_arch.py:35-56); 2: followed by pixel-shuffle(2); res (NULL or [B,Cout,H,W]) is
+ * added in mode 0. */
+int jirf_op_conv3x3(const float* x, const float* w_host, const float* bias_host, const float* res,
+                    float* y, int B, int Cin, int Cout, int H, int W, int mode, void* stream);
+/* Depthwise 3x3, zero pad 1 (hint_arch.py:163-171,307-315).  w [C,1,3,3] and bias (or NULL) are
+ * DEVICE arrays.  gate != 0: C must be even and y[b,c] = gelu(dw(x)[b,c]) * dw(x)[b,c+C/2]
+ * for c < C/2 (FeedForward.execute hint_arch.py:182-184). */
+int jirf_op_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int B, int C,
+                      int H, int W, int gate, void* stream);
+/* Per-pixel LayerNorm over channels (hint_arch.py:98-145). kind 1 WithBias, 2 BiasFree. */
+int jirf_op_layernorm(const float* x, const float* w, const float* b, float* y, int B, int C, int P,
+                      int kind, void* stream);
+/* HINT channel attention core (Attention.execute hint_arch.py:351-399 without the two convs and
+ * without the intra-modulator): qkv [B,3C,P] device; writes out [B,C,P] (sorted channel order),
+ * tcache [B,C,P] (= normalised q + k in sorted order), perm [G,C] int32, att [B,C,C]
+ * (block-diagonal attention after inter-modulation), cache_out [G,C,C].  cache_in NULL = None,
+ * else [G,Cc,Cc].  G = B (per-image) or 1 (coupled).  params_host: the reference tensors
+ * temperature[4], then for g in 0..3 conv_width.weight[2c,c], conv_width.bias[2c],
+ * gating_conv.weight[c,c], gating_conv.bias[c], concatenated (host). */
+int jirf_op_hint_attention_core(const float* qkv, const float* params_host, const float* cache_in,
+                                int cache_c, float* out, float* tcache, int32_t* perm, float* att,
+                                float* cache_out, int B, int C, int P, int batch_mode,
+                                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JIRF_HIP_H */

@@ -1,0 +1,115 @@
+"""Synthetic weights in the reference's state-dict key/shape layout (test infrastructure).
+
+No checkpoint ships with the reference, so tests and benchmarks use seeded
+random weights.  Conv / linear kernels are N(0, gain^2 / fan_in) so activations
+stay O(1) through the whole depth; every per-channel parameter (LayerNorm
+weight and bias, temperature, conv biases) is randomised so that a kernel which
+applies one to the wrong channel is caught.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from .hint_oracle import default_config as hint_default_config, stage_plan as hint_stage_plan
+
+
+class _Gen:
+    def __init__(self, seed: int, gain: float = 1.0):
+        self.rng = np.random.default_rng(seed)
+        self.gain = gain
+        self.sd = OrderedDict()
+
+    def kernel(self, key, shape, fan_in=None):
+        if fan_in is None:
+            fan_in = int(np.prod(shape[1:]))
+        std = self.gain / np.sqrt(max(fan_in, 1))
+        self.sd[key] = (self.rng.standard_normal(shape) * std).astype(np.float32)
+
+    def vec(self, key, n, mean=0.0, std=0.1):
+        self.sd[key] = (mean + std * self.rng.standard_normal(n)).astype(np.float32)
+
+    def uniform(self, key, shape, lo, hi):
+        self.sd[key] = self.rng.uniform(lo, hi, shape).astype(np.float32)
+
+
+def make_hint_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0,
+                    mod_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """HINT state dict (hint_arch.py:494-655 constructors). `mod_gain` scales the
+    inter-modulator kernels; > 1 drives the cache's floor-division off zero."""
+    cfg = cfg or hint_default_config()
+    g = _Gen(seed, gain)
+    dim, bias = cfg["dim"], cfg.get("bias", False)
+    with_bias_ln = cfg.get("ln_type", "WithBias") != "BiasFree"
+    ffn = cfg["ffn_expansion_factor"]
+    cin, cout = cfg.get("inp_channels", 3), cfg.get("out_channels", 3)
+
+    def conv(key, co, ci, k, b):
+        g.kernel(key + ".weight", (co, ci, k, k))
+        if b:
+            g.vec(key + ".bias", co, 0.0, 0.05)
+
+    def ln(key, c):
+        g.vec(key + ".body.weight", c, 1.0, 0.1)
+        if with_bias_ln:
+            g.vec(key + ".body.bias", c, 0.0, 0.1)
+
+    def block(pre, c, is_att):
+        if is_att:
+            ln(pre + ".norm1", c)
+            a = pre + ".attn"
+            g.uniform(a + ".temperature", (4, 1, 1), 0.5, 2.0)
+            conv(a + ".qkv", 3 * c, c, 1, bias)
+            g.kernel(a + ".qkv_dwconv.weight", (3 * c, 1, 3, 3))
+            if bias:
+                g.vec(a + ".qkv_dwconv.bias", 3 * c, 0.0, 0.05)
+            conv(a + ".project_out", c, c, 1, bias)
+            im = a + ".intra_modulator"
+            g.kernel(im + ".down.weight", (c // 2, c, 1)); g.vec(im + ".down.bias", c // 2, 0, 0.05)
+            g.kernel(im + ".up.weight", (c, c // 2, 1)); g.vec(im + ".up.bias", c, 0, 0.05)
+            g.kernel(im + ".gating_conv.weight", (c, c, 1)); g.vec(im + ".gating_conv.bias", c, 0, 0.05)
+            for gi, r in enumerate((1, 2, 2, 3)):
+                cg = r * c // 8
+                m = f"{a}.inter_modulator{gi + 1}"
+                g.kernel(m + ".conv_width.weight", (2 * cg, cg, 1))
+                g.sd[m + ".conv_width.weight"] *= np.float32(mod_gain)
+                g.vec(m + ".conv_width.bias", 2 * cg, 0, 0.05 * mod_gain)
+                g.kernel(m + ".gating_conv.weight", (cg, cg, 1))
+                g.sd[m + ".gating_conv.weight"] *= np.float32(mod_gain)
+                g.vec(m + ".gating_conv.bias", cg, 0, 0.05 * mod_gain)
+        ln(pre + ".norm2", c)
+        h = int(c * ffn)
+        f = pre + ".ffn"
+        conv(f + ".project_in", 2 * h, c, 1, bias)
+        g.kernel(f + ".dwconv.weight", (2 * h, 1, 3, 3))
+        if bias:
+            g.vec(f + ".dwconv.bias", 2 * h, 0.0, 0.05)
+        conv(f + ".project_out", c, h, 1, bias)
+
+    g.kernel("patch_embed.proj.weight", (dim, cin, 3, 3))
+    for name, n, mult, is_att in hint_stage_plan(cfg):
+        for i in range(n):
+            block(f"{name}.{i}", dim * mult, is_att)
+    g.kernel("down1_2.body.0.weight", (dim // 2, dim, 3, 3))
+    g.kernel("down2_3.body.0.weight", (dim, 2 * dim, 3, 3))
+    g.kernel("down3_4.body.0.weight", (2 * dim, 4 * dim, 3, 3))
+    g.kernel("up4_3.body.0.weight", (16 * dim, 8 * dim, 3, 3))
+    g.kernel("up3_2.body.0.weight", (8 * dim, 4 * dim, 3, 3))
+    g.kernel("up2_1.body.0.weight", (4 * dim, 2 * dim, 3, 3))
+    conv("reduce_chan_level3", 4 * dim, 8 * dim, 1, bias)
+    conv("reduce_chan_level2", 2 * dim, 4 * dim, 1, bias)
+    if cfg.get("dual_pixel_task", False):
+        conv("skip_conv", 2 * dim, dim, 1, bias)
+    conv("output", cout, 2 * dim, 3, bias)
+    return g.sd
+
+
+def synthetic_images(b: int, h: int, w: int, seed: int = 0, sigma: float | None = None) -> np.ndarray:
+    """Uniform [0,1) NCHW fp32 images; with `sigma`, Gaussian noise sigma/255 is
+    added without clamping (Denoising/test_gaussian_color_denoising_HINT.py:160-163)."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((b, 3, h, w), dtype=np.float32)
+    if sigma is not None:
+        x = (x + rng.normal(0.0, sigma / 255.0, x.shape)).astype(np.float32)
+    return x

@@ -1,0 +1,113 @@
+"""Known-answer tests of the single-kernel entry points against the oracle's ops (GPU)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import common as oc
+from tests.gpu_util import call, dev, hptr, max_abs, ptr, stream
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(7)
+
+
+def rnd(*shape, scale=1.0):
+    return (RNG.standard_normal(shape) * scale).astype(np.float32)
+
+
+# fp32 MFMA and oneDNN/MKL sum in different orders: tolerance scales with sqrt(K)
+def gemm_tol(k, mag=1.0):
+    return 2e-6 * np.sqrt(k) * mag + 1e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,P", [
+    (1, 48, 254, 96 * 64),      # level-1 project_in of HINT (odd Cout)
+    (2, 127, 48, 1000),         # odd K, P not a multiple of the tile
+    (1, 384, 1152, 32 * 32),    # latent qkv
+    (3, 96, 96, 77),            # P not a multiple of 4 -> scalar loader
+    (1, 1021, 384, 256),        # latent project_out (odd K)
+    (1, 16, 3, 4096),           # tiny Cout
+    (2, 192, 510, 128 * 128),   # big enough for the 128x128 tile
+])
+def test_conv1x1(B, Cin, Cout, P):
+    x, w, b = rnd(B, Cin, P), rnd(Cout, Cin, scale=Cin ** -0.5), rnd(Cout)
+    res = rnd(B, Cout, P)
+    ref = torch.einsum("oi,bip->bop", torch.from_numpy(w), torch.from_numpy(x)) + torch.from_numpy(b)[None, :, None]
+    xd, rd = dev(x), dev(res)
+    y = torch.empty(B, Cout, P, device="cuda")
+    call("jirf_op_conv1x1", ptr(xd), hptr(w), hptr(b), None, ptr(y), B, Cin, Cout, P, stream())
+    assert max_abs(y.cpu(), ref) < gemm_tol(Cin, 4)
+    call("jirf_op_conv1x1", ptr(xd), hptr(w), None, ptr(rd), ptr(y), B, Cin, Cout, P, stream())
+    assert max_abs(y.cpu(), ref - torch.from_numpy(b)[None, :, None] + torch.from_numpy(res)) < gemm_tol(Cin, 4)
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("B,C,Cout,P", [(2, 48, 144, 2048), (1, 384, 254, 130), (1, 96, 510, 4096)])
+def test_ln_conv1x1(kind, B, C, Cout, P):
+    x = rnd(B, C, P) * 2 + 0.5
+    lw, lb = (1 + 0.1 * rnd(C)), 0.1 * rnd(C)
+    w = rnd(Cout, C, scale=C ** -0.5)
+    n = oc.channel_layernorm(torch.from_numpy(x).reshape(B, C, P, 1), torch.from_numpy(lw), torch.from_numpy(lb), kind == 1)
+    ref = torch.einsum("oi,bip->bop", torch.from_numpy(w), n.reshape(B, C, P))
+    y = torch.empty(B, Cout, P, device="cuda")
+    xd, lwd, lbd = dev(x), dev(lw), dev(lb)
+    call("jirf_op_ln_conv1x1", ptr(xd), ptr(lwd), ptr(lbd), kind, hptr(w), ptr(y), B, C, Cout, P, stream())
+    assert max_abs(y.cpu(), ref) < gemm_tol(C, 8)
+    yl = torch.empty(B, C, P, device="cuda")
+    call("jirf_op_layernorm", ptr(xd), ptr(lwd), ptr(lbd), ptr(yl), B, C, P, kind, stream())
+    assert max_abs(yl.cpu(), n.reshape(B, C, P)) < 2e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 3, 48, 40, 56), (2, 48, 24, 32, 48), (1, 96, 192, 16, 24),
+                                            (1, 96, 3, 24, 40), (1, 384, 768, 6, 10)])
+def test_conv3x3(mode, B, Cin, Cout, H, W):
+    if mode == 2 and Cout % 4:
+        pytest.skip("pixel shuffle needs Cout % 4 == 0")
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1)
+    res = None
+    if mode == 1:
+        ref = oc.pixel_unshuffle2(ref)
+    elif mode == 2:
+        ref = oc.pixel_shuffle2(ref)
+    else:
+        res = rnd(B, Cout, H, W)
+        ref = ref + torch.from_numpy(res)
+    y = torch.empty(ref.shape, device="cuda")
+    xd = dev(x)
+    rd = None if res is None else dev(res)
+    call("jirf_op_conv3x3", ptr(xd), hptr(w), None, ptr(rd), ptr(y), B, Cin, Cout, H, W, mode, stream())
+    assert max_abs(y.cpu(), ref) < gemm_tol(9 * Cin, 4)
+
+
+def test_pixel_shuffle_bit_exact():
+    """(Un)shuffle is pure indexing: a conv with an identity centre tap must reproduce it bit for bit."""
+    B, C, H, W = 1, 8, 16, 24
+    x = rnd(B, C, H, W)
+    w = np.zeros((C, C, 3, 3), np.float32)
+    for c in range(C):
+        w[c, c, 1, 1] = 1.0
+    xd = dev(x)
+    for mode, fn in ((1, oc.pixel_unshuffle2), (2, oc.pixel_shuffle2)):
+        ref = fn(torch.from_numpy(x))
+        y = torch.empty(ref.shape, device="cuda")
+        call("jirf_op_conv3x3", ptr(xd), hptr(w), None, None, ptr(y), B, C, C, H, W, mode, stream())
+        assert np.array_equal(y.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("gate", [0, 1])
+@pytest.mark.parametrize("B,C,H,W,bias", [(1, 254, 40, 56, False), (2, 30, 17, 70, True), (1, 144, 64, 64, False),
+                                          (1, 6, 5, 3, True)])
+def test_dwconv3x3(gate, B, C, H, W, bias):
+    x, w = rnd(B, C, H, W), rnd(C, 1, 3, 3, scale=1 / 3)
+    b = rnd(C) if bias else None
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None if b is None else torch.from_numpy(b), padding=1, groups=C)
+    if gate:
+        x1, x2 = ref.chunk(2, dim=1)
+        ref = oc.gelu(x1) * x2
+    y = torch.empty(ref.shape, device="cuda")
+    xd, wd = dev(x), dev(w)
+    bd = None if b is None else dev(b)
+    call("jirf_op_dwconv3x3", ptr(xd), ptr(wd), ptr(bd), ptr(y), B, C, H, W, gate, stream())
+    assert max_abs(y.cpu(), ref) < 5e-6
