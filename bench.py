@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Throughput of the HINT inference forward on MI355X (BASELINE.json configs[1]).
+
+A step = one forward of libjirf_hip's HINT over one batch of synthetic 256x256 RGB crops with
+sigma=50 Gaussian noise, fp32, inputs and outputs resident in HBM.  Every image is an
+independent cold-start call (the reference's test scripts run B=1; `per_image` batch mode is
+bit-for-bit B separate calls), so ranks shard by image and no collective touches the data path.
+
+Prints ONE JSON line on rank 0 (see --help for the knobs).  Extra legs, N=1 only:
+  roofline      the dominant kernel (the fp32-MFMA pointwise-conv GEMM family) timed with HIP
+                events on the launch stream in a second pass over the same steps
+  cpu_baseline  the CPU oracle (a torch-CPU restatement of the reference forward; the reference's
+                Jittor runtime is not installable here) on a bounded sample, host cores stated
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "image-restoration_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f32), dense
+HBM_PEAK_GBS = 8000.0
+
+
+def hint_flops_per_image(cfg, h, w):
+    """2*MAC count of one HINT forward (constructor shapes of hint_arch.py of the reference)."""
+    d, nb, ffn = cfg["dim"], cfg["num_blocks"], cfg["ffn_expansion_factor"]
+    p1 = h * w
+    total = 0.0
+
+    def block(c, p, att):
+        hid = int(c * ffn)
+        f = 2 * c * 2 * hid * p + 18 * 2 * hid * p + 2 * hid * c * p
+        if att:
+            f += 2 * c * 3 * c * p + 18 * 3 * c * p + 2 * c * c * p          # qkv, dw, project_out
+            f += 2 * c * c * p                                              # corrcoef
+            gs = [int(r / 8 * c) for r in (1, 2, 2, 3)]
+            f += sum(4 * g * g * p for g in gs)                            # QK^T + AV
+            f += 2 * c * c * p + 2 * c * (c // 2) * p * 2                   # intra modulator
+        return f
+
+    total += 2 * 27 * d * p1
+    plan = [(nb[0], d, p1, False), (nb[1], 2 * d, p1 // 4, False), (nb[2], 4 * d, p1 // 16, False),
+            (nb[1], 8 * d, p1 // 64, True), (nb[2], 4 * d, p1 // 16, True), (nb[1], 2 * d, p1 // 4, True),
+            (nb[0], 2 * d, p1, True), (cfg["num_refinement_blocks"], 2 * d, p1, True)]
+    for n, c, p, att in plan:
+        total += n * block(c, p, att)
+    total += 2 * 9 * d * (d // 2) * p1 + 2 * 9 * 2 * d * d * (p1 // 4) + 2 * 9 * 4 * d * 2 * d * (p1 // 16)
+    total += 2 * 9 * 8 * d * 16 * d * (p1 // 64) + 2 * 9 * 4 * d * 8 * d * (p1 // 16) + 2 * 9 * 2 * d * 4 * d * (p1 // 4)
+    total += 2 * 8 * d * 4 * d * (p1 // 16) + 2 * 4 * d * 2 * d * (p1 // 4)
+    total += 2 * 9 * 2 * d * 3 * p1
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="256x256 crops per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oracle import hint_oracle as ho
+    from oracle.weights import make_hint_state, synthetic_images
+    from basicsr.models.archs import define_network
+
+    cfg = ho.default_config()
+    sd = make_hint_state(cfg, seed=1, gain=0.6)
+    net = define_network(dict(cfg, type="HINT"))
+    net.load_state_dict(sd)
+    net.cuda(local_rank).eval()
+    net.batch_mode = "per_image"
+
+    B, S = args.batch, args.size
+    x = torch.from_numpy(synthetic_images(B, S, S, seed=100 + rank, sigma=50)).cuda()
+
+    def step():
+        net.qv_cache = None          # every image is a cold-start call
+        return net(x)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(y).all()), "non-finite output"
+
+    mp_per_step = world * B * S * S / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+    value = mp_per_step / (ms_per_step / 1e3)
+    flops_img = hint_flops_per_image(cfg, S, S)
+    out = {
+        "metric": "restored megapixels/sec (node), HINT sigma=50 denoising forward, 256x256 crops",
+        "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "ms_per_image": round(ms_per_step / B, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (uniform [0,1) RGB + N(0,(50/255)^2) noise; seeded random weights in the reference key layout)",
+        "config": {"workload": f"HINT (dim 48, blocks [4,6,6,8], refine 4, ffn 2.66) forward on a batch of {B} "
+                               f"{S}x{S} RGB crops per GPU, cold-start per image, fp32",
+                   "batch_per_gpu": B, "height": S, "width": S, "sharding": "images round-robin over ranks, no collective"},
+        "model_tflops_per_s": round(world * B * flops_img / (ms_per_step / 1e3) / 1e12, 2),
+        "frac_of_f32_mfma_peak": round(B * flops_img / (ms_per_step / 1e3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        nat = net.native()
+        nat.enable_kernel_timing(True)
+        acc = {}
+        for _ in range(args.steps):
+            step()
+            torch.cuda.synchronize()
+            for k in nat.kernel_times():
+                a = acc.setdefault(k["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                for f in ("ms", "flops", "bytes", "launches"):
+                    a[f] += k[f]
+        nat.enable_kernel_timing(False)
+        tot_ms = sum(a["ms"] for a in acc.values())
+        dom = max(acc.items(), key=lambda kv: kv[1]["ms"])
+        name, a = dom
+        gemm_like = name.startswith("gemm") or name == "hint_chan_stats"
+        if gemm_like:
+            ach = a["flops"] / (a["ms"] / 1e3) / 1e12
+            roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
+        else:
+            ach = a["bytes"] / (a["ms"] / 1e3) / 1e9
+            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        roof.update({"traffic": None, "launches_per_step": a["launches"] // args.steps,
+                     "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
+                     "share_of_device_time": round(a["ms"] / tot_ms, 4)})
+        out["roofline"] = roof
+        out["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                              "launches_per_step": v["launches"] // args.steps,
+                              "tflops": round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) if v["ms"] > 0 else 0,
+                              "gbs": round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) if v["ms"] > 0 else 0}
+                          for k, v in sorted(acc.items(), key=lambda kv: -kv[1]["ms"])}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample: one 256x256 image through the oracle on the host cores of this box
+        cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        torch.set_num_threads(cores)
+        xs = x[:1].cpu()
+        t0 = time.perf_counter()
+        ho.hint_forward(sd, xs, cfg, None)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(S * S / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
+                               "sample": f"1 image {S}x{S} through oracle/hint_oracle.py (torch-CPU fp32), {dt:.1f} s"}
+
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -137,18 +137,19 @@ def layer_cache(att: List[torch.Tensor], c: int, sw: HintSwitches) -> torch.Tens
     return total.squeeze(1)
 
 
-def hmha(p: Params, pre: str, x: torch.Tensor, cache: Optional[torch.Tensor],
-         sw: HintSwitches, tap: Tap = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Attention.execute (:345-405). x is the normalised input [B,C,H,W]."""
-    b, c, h, w = x.shape
-    qkv = conv3x3(conv1x1(x, p[pre + ".qkv.weight"], p.get(pre + ".qkv.bias")),
-                  p[pre + ".qkv_dwconv.weight"], p.get(pre + ".qkv_dwconv.bias"), groups=3 * c)
-    q, k, v = [t.reshape(b, c, h * w) for t in qkv.chunk(3, dim=1)]
-
+def hmha_core(p: Params, pre: str, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+              cache: Optional[torch.Tensor], sw: HintSwitches, tap: Tap = None,
+              forced_order: Optional[torch.Tensor] = None):
+    """The part of Attention.execute between the convolutions and the intra-modulator
+    (:354-399).  q, k, v are [B,C,L].  Returns (out [B,C,L] in sorted channel order,
+    tcache [B,C,L], att list, new cache [1,C,C], channel order)."""
+    c = q.shape[1]
     order, sim = regroup_permutation(q, sw.regroup_precision)
     if tap:
         tap(pre + ".perm", order.clone())
         tap(pre + ".mean_similarity", sim.clone())
+    if forced_order is not None:
+        order = forced_order
     qs, ks, vs = q[:, order], k[:, order], v[:, order]
 
     sizes = group_sizes(c)
@@ -183,8 +184,17 @@ def hmha(p: Params, pre: str, x: torch.Tensor, cache: Optional[torch.Tensor],
         cache = cache * CACHE_MOMENTUM + upd * (1 - CACHE_MOMENTUM)
     else:
         cache = upd * CACHE_MOMENTUM
+    return torch.cat(outs, dim=1), tcache, att, cache, order          # out stays in sorted order
 
-    out = torch.cat(outs, dim=1)                                    # stays in sorted channel order
+
+def hmha(p: Params, pre: str, x: torch.Tensor, cache: Optional[torch.Tensor],
+         sw: HintSwitches, tap: Tap = None, forced_order=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Attention.execute (:345-405). x is the normalised input [B,C,H,W]."""
+    b, c, h, w = x.shape
+    qkv = conv3x3(conv1x1(x, p[pre + ".qkv.weight"], p.get(pre + ".qkv.bias")),
+                  p[pre + ".qkv_dwconv.weight"], p.get(pre + ".qkv_dwconv.bias"), groups=3 * c)
+    q, k, v = [t.reshape(b, c, h * w) for t in qkv.chunk(3, dim=1)]
+    out, tcache, _, cache, _ = hmha_core(p, pre, q, k, v, cache, sw, tap, forced_order)
     out = intra_modulation(p, pre + ".intra_modulator", out, tcache) + out
     out = conv1x1(out.reshape(b, c, h, w), p[pre + ".project_out.weight"],
                   p.get(pre + ".project_out.bias"))
@@ -200,12 +210,12 @@ def gdfn(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
 
 
 def transformer_block(p: Params, pre: str, x: torch.Tensor, cache, is_att: bool,
-                      with_bias_ln: bool, sw: HintSwitches, tap: Tap = None):
+                      with_bias_ln: bool, sw: HintSwitches, tap: Tap = None, forced_order=None):
     """TransformerBlock.execute (:426-434)."""
     if is_att:
         n1 = channel_layernorm(x, p[pre + ".norm1.body.weight"], p.get(pre + ".norm1.body.bias"),
                                with_bias_ln)
-        a, cache = hmha(p, pre + ".attn", n1, cache, sw, tap)
+        a, cache = hmha(p, pre + ".attn", n1, cache, sw, tap, forced_order)
         x = x + a
     n2 = channel_layernorm(x, p[pre + ".norm2.body.weight"], p.get(pre + ".norm2.body.bias"),
                            with_bias_ln)
@@ -227,11 +237,14 @@ def upsample(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
 
 def hint_forward(state: dict, x: torch.Tensor, cfg: Optional[dict] = None,
                  qv_cache: Optional[torch.Tensor] = None,
-                 sw: Optional[HintSwitches] = None, tap: Tap = None):
+                 sw: Optional[HintSwitches] = None, tap: Tap = None,
+                 forced_orders: Optional[dict] = None):
     """HINT.execute (:657-706) -> (y, qv_cache_out).
 
     A call with B > 1 is the reference's literal batched call: the regroup
-    statistics and the cache use batch means (:245, :282).
+    statistics and the cache use batch means (:245, :282).  `forced_orders`
+    ({block name: channel order}) replaces the argsort of the named blocks (a
+    checker's tool: the argsort is discontinuous in its input).
     """
     cfg = cfg or default_config()
     sw = sw or HintSwitches()
@@ -243,7 +256,8 @@ def hint_forward(state: dict, x: torch.Tensor, cfg: Optional[dict] = None,
     def run_stage(name, n, t, is_att):
         nonlocal cache
         for i in range(n):
-            t, cache = transformer_block(p, f"{name}.{i}", t, cache, is_att, wb, sw, tap)
+            fo = None if forced_orders is None else forced_orders.get(f"{name}.{i}")
+            t, cache = transformer_block(p, f"{name}.{i}", t, cache, is_att, wb, sw, tap, fo)
         return t
 
     plan = {s[0]: s for s in stage_plan(cfg)}
