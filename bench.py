@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--detail", default=None, help="write the per-shape kernel table to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,15 +145,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_roofline:
         nat = net.native()
         nat.enable_kernel_timing(True)
-        acc = {}
+        acc, detail = {}, {}
         for _ in range(args.steps):
             step()
             torch.cuda.synchronize()
             for k in nat.kernel_times():
-                a = acc.setdefault(k["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-                for f in ("ms", "flops", "bytes", "launches"):
-                    a[f] += k[f]
+                # labels are "<kernel family> <shape>": the roofline leg aggregates per family
+                for table, key in ((acc, k["name"].split(" ")[0]), (detail, k["name"])):
+                    a = table.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                    for f in ("ms", "flops", "bytes", "launches"):
+                        a[f] += k[f]
         nat.enable_kernel_timing(False)
+        if args.detail:
+            with open(args.detail, "w") as fh:
+                for k, v in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
+                    fh.write(f"{v['ms'] / args.steps:9.3f} ms/step  {v['launches'] // args.steps:4d} launches  "
+                             f"{v['flops'] / (v['ms'] / 1e3) / 1e12 if v['ms'] else 0:7.2f} TFLOP/s  "
+                             f"{v['bytes'] / (v['ms'] / 1e3) / 1e9 if v['ms'] else 0:8.1f} GB/s  {k}\n")
         tot_ms = sum(a["ms"] for a in acc.values())
         dom = max(acc.items(), key=lambda kv: kv[1]["ms"])
         name, a = dom

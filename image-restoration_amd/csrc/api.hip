@@ -150,6 +150,7 @@ int jirf_net_finalize(jirf_net* net) {
 int jirf_net_plan(jirf_net* net, int B, int H, int W, int batch_mode, size_t* workspace_bytes) {
   return guarded([&] {
     Net* n = get(net);
+    JIRF_REQUIRE(n->finalized, JIRF_ESTATE, "plan before finalize");
     JIRF_HIP_CHECK(hipSetDevice(n->device));
     const size_t bytes = n->plan(B, H, W, batch_mode);
     if (workspace_bytes) *workspace_bytes = bytes;

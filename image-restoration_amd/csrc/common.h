@@ -160,6 +160,8 @@ KernelClock* current_clock();
 void set_current_clock(KernelClock* c);
 // RAII marker placed around a launch: records (name, flops, bytes) and, when a clock is
 // installed, brackets the launch with HIP events.
+// Returns a pointer that stays valid for the life of the process (labels carry shapes).
+const char* intern_label(const char* fmt, ...);
 struct Scope {
   Scope(const char* name, double flops, double bytes, hipStream_t s);
   ~Scope();

@@ -8,9 +8,13 @@
 // MFMA column (lane) index: loads and stores are 128-byte row segments.  Arithmetic is
 // v_mfma_f32_32x32x2_f32: exact fp32 fma chains, k-ordered.
 //
-// Tile: BM output channels x BN pixels per 256-thread workgroup (2 x 2 waves), K stepped by 16
-// through a double-buffered LDS image [k][m] / [k][n]; operands are staged through registers so
-// the loader can mask, gather, normalise (LayerNorm folded into the load) or shift (3x3 taps).
+// Tile: a workgroup of WAVES_M x WAVES_N waves, each wave owning TM x TN accumulator tiles of
+// 32 x 32; K stepped by 16 through a double-buffered LDS image [k][m] / [k][n]; operands are
+// staged through registers so the loader can mask, gather, normalise (LayerNorm folded into the
+// load) or shift (3x3 taps).  The 96-row tile exists because every channel count of the
+// Restormer-family nets is 48 * 2^k: 96, 192, 288, 384, 576, 1152 are all multiples of 96.
+#include <type_traits>
+
 #include "common.h"
 
 namespace jirf {
@@ -30,23 +34,26 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return base + local;
 }
 
-template <int BM, int BN, int LOADER, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a, const int tiles_m,
-                                                   const int tiles_n) {
+template <int WAVES_M, int WAVES_N, int TM, int TN, int LOADER, bool VEC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const GemmArgs a,
+                                                                        const int tiles_m,
+                                                                        const int tiles_n) {
   constexpr int BK = GEMM_BK;
-  constexpr int WM = BM / 2, WN = BN / 2;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int XS = (BK * BN / 4 + 255) / 256;  // float4 slots per thread, activation tile
-  constexpr int WS = (BK * BM / 4 + 255) / 256;  // float4 slots per thread, weight tile
-  constexpr bool X_FULL = (BK * BN / 4) % 256 == 0;
-  constexpr bool W_FULL = (BK * BM / 4) % 256 == 0;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int WM = TM * 32, WN = TN * 32;
+  constexpr int BM = WAVES_M * WM, BN = WAVES_N * WN;
+  constexpr int XSLOTS = BK * BN / 4, WSLOTS = BK * BM / 4;
+  constexpr int XS = (XSLOTS + NT - 1) / NT;  // float4 slots per thread, activation tile
+  constexpr int WS = (WSLOTS + NT - 1) / NT;  // float4 slots per thread, weight tile
+  constexpr bool X_FULL = XSLOTS % NT == 0;
+  constexpr bool W_FULL = WSLOTS % NT == 0;
 
   __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, half = lane >> 5;
 
   const int per_img = tiles_m * tiles_n;
@@ -67,10 +74,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a, const int t
   bool x_on[XS];
 #pragma unroll
   for (int i = 0; i < XS; ++i) {
-    const int s = tid + i * 256;
+    const int s = tid + i * NT;
     x_row[i] = s / (BN / 4);
     x_col[i] = (s - x_row[i] * (BN / 4)) * 4;
-    x_on[i] = X_FULL || s < BK * BN / 4;
+    x_on[i] = X_FULL || s < XSLOTS;
   }
   float4 ln_mu[XS], ln_rs[XS];
   int cv_yx[XS][4];
@@ -149,8 +156,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a, const int t
           v.z = v.z * rs.z * g;
           v.w = v.w * rs.w * g;
         }
-        // columns past the image must stay zero (rs == 0 there already zeroes the product,
-        // but the bias term would not)
+        // columns past the image must stay zero (the bias term would otherwise leak in)
         if (p >= P) v.x = 0.f;
         if (p + 1 >= P) v.y = 0.f;
         if (p + 2 >= P) v.z = 0.f;
@@ -160,11 +166,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a, const int t
     }
   };
   auto load_w = [&](int kt, int i) -> float4 {
-    const int s = tid + i * 256;
-    if (!W_FULL && s >= BK * BM / 4) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s = tid + i * NT;
+    if (!W_FULL && s >= WSLOTS) return make_float4(0.f, 0.f, 0.f, 0.f);
     const int row = s / (BM / 4);
-    const int col = (s - row * (BM / 4)) * 4;
-    return *reinterpret_cast<const float4*>(wt + (long)(kt * BK + row) * a.Mpad + m0 + col);
+    const int col = m0 + (s - row * (BM / 4)) * 4;
+    if (col >= a.Mpad) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(wt + (long)(kt * BK + row) * a.Mpad + col);
   };
   auto store_tiles = [&](int buf, const float4* xr, const float4* wr) {
 #pragma unroll
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a, const int t
       if (x_on[i]) *reinterpret_cast<float4*>(&Bs[buf][x_row[i] * BN + x_col[i]]) = xr[i];
 #pragma unroll
     for (int i = 0; i < WS; ++i) {
-      const int s = tid + i * 256;
-      if (W_FULL || s < BK * BM / 4) *reinterpret_cast<float4*>(&As[buf][s * 4]) = wr[i];
+      const int s = tid + i * NT;
+      if (W_FULL || s < WSLOTS) *reinterpret_cast<float4*>(&As[buf][s * 4]) = wr[i];
     }
   };
 
@@ -221,69 +228,107 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a, const int t
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
+  // Per 32 x 32 accumulator tile: first gather everything the epilogue reads (so the 16 loads
+  // are in flight together — output and residual may be the same buffer, which keeps the
+  // compiler from hoisting them itself), then combine and store.
   const int M = a.M;
-  const int epi = a.epi;
   float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * WN + j * 32 + l31;
-    if (col >= P) continue;
-    int py = 0, px = 0;
-    if (epi == EP_UNSHUFFLE || epi == EP_SHUFFLE) {
-      py = col / a.W;
-      px = col - py * a.W;
-    }
+  auto run_epilogue = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int row0 = m0 + wm * WM + i * 32 + 4 * half;
+      float bias_r[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row >= M) continue;
-        float v = acc[i][j][r];
-        if (a.bias) v += a.bias[row];
-        switch (epi) {
-          case EP_STORE:
-            yb[(long)row * P + col] = v;
-            break;
-          case EP_RESID:
-            yb[(long)row * P + col] = v + a.r.p[(long)b * a.r.bs + (long)row * P + col];
-            break;
-          case EP_GELU_MUL:
-            yb[(long)row * P + col] =
-                gelu_erf(v) * a.r.p[(long)b * a.r.bs + (long)row * P + col];
-            break;
-          case EP_AV_INTRA: {
-            const int src = a.kidx[(long)(b / a.imgs_per_group) * M + row];
-            const float qv = a.q.p[(long)b * a.q.bs + (long)src * P + col];
-            const float kv = a.k.p[(long)b * a.k.bs + (long)src * P + col];
-            yb[(long)row * P + col] = v;
-            a.y2.p[(long)b * a.y2.bs + (long)row * P + col] =
-                v + (qv * a.rq[(long)b * M + src] + kv * a.rk[(long)b * M + src]);
-            break;
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        bias_r[r] = (a.bias && row < M) ? a.bias[row] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + l31;
+        if (col >= P) continue;
+        float aux[16];
+        if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL) {
+          const float* __restrict__ rp = a.r.p + (long)b * a.r.bs + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            aux[r] = row < M ? rp[(long)row * P] : 0.f;
           }
-          case EP_UNSHUFFLE: {
+        }
+        if constexpr (EPI == EP_AV_INTRA) {
+          const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
+          const float* __restrict__ qp = a.q.p + (long)b * a.q.bs + col;
+          const float* __restrict__ kp = a.k.p + (long)b * a.k.bs + col;
+          int src[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            src[r] = row < M ? perm[row] : 0;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            aux[r] = qp[(long)src[r] * P] * a.rq[(long)b * M + src[r]] +
+                     kp[(long)src[r] * P] * a.rk[(long)b * M + src[r]];
+        }
+        int py = 0, px = 0;
+        if constexpr (EPI == EP_UNSHUFFLE || EPI == EP_SHUFFLE) {
+          py = col / a.W;
+          px = col - py * a.W;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2);
+          if (row >= M) continue;
+          const float v = acc[i][j][r] + bias_r[r];
+          if constexpr (EPI == EP_STORE) {
+            yb[(long)row * P + col] = v;
+          } else if constexpr (EPI == EP_RESID) {
+            yb[(long)row * P + col] = v + aux[r];
+          } else if constexpr (EPI == EP_GELU_MUL) {
+            yb[(long)row * P + col] = gelu_erf(v) * aux[r];
+          } else if constexpr (EPI == EP_AV_INTRA) {
+            yb[(long)row * P + col] = v;
+            a.y2.p[(long)b * a.y2.bs + (long)row * P + col] = v + aux[r];
+          } else if constexpr (EPI == EP_UNSHUFFLE) {
             const int oc = 4 * row + 2 * (py & 1) + (px & 1);
             yb[(long)oc * (P >> 2) + (long)(py >> 1) * (a.W >> 1) + (px >> 1)] = v;
-            break;
-          }
-          case EP_SHUFFLE: {
+          } else if constexpr (EPI == EP_SHUFFLE) {
             const int oc = row >> 2;
             const int oy = 2 * py + ((row >> 1) & 1), ox = 2 * px + (row & 1);
             yb[(long)oc * (4L * P) + (long)oy * (2 * a.W) + ox] = v;
-            break;
           }
         }
       }
     }
+  };
+  // only the loader/epilogue pairs the networks use are instantiated
+  const int epi = a.epi;
+  if constexpr (LOADER == LD_GATHER) {
+    run_epilogue(std::integral_constant<int, EP_AV_INTRA>{});
+  } else if constexpr (LOADER == LD_LN) {
+    run_epilogue(std::integral_constant<int, EP_STORE>{});
+  } else if constexpr (LOADER == LD_CONV3) {
+    if (epi == EP_UNSHUFFLE) run_epilogue(std::integral_constant<int, EP_UNSHUFFLE>{});
+    else if (epi == EP_SHUFFLE) run_epilogue(std::integral_constant<int, EP_SHUFFLE>{});
+    else if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
+    else run_epilogue(std::integral_constant<int, EP_STORE>{});
+  } else {
+    if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
+    else if (epi == EP_GELU_MUL) run_epilogue(std::integral_constant<int, EP_GELU_MUL>{});
+    else run_epilogue(std::integral_constant<int, EP_STORE>{});
   }
 }
 
-template <int BM, int BN>
+template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_tile(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.P + BN - 1) / BN;
-  const dim3 grid((unsigned)(tiles_m * tiles_n * a.B)), block(256);
-#define JIRF_GEMM_CASE(LD, V) \
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, LD, V>), grid, block, 0, s, a, tiles_m, tiles_n)
+  const dim3 grid((unsigned)(tiles_m * tiles_n * a.B)), block(64 * WAVES_M * WAVES_N);
+#define JIRF_GEMM_CASE(LD, V)                                                                   \
+  hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, TM, TN, LD, V>), grid, block, 0, s, a, tiles_m, \
+                     tiles_n)
   switch (loader) {
     case LD_PLAIN:
       if (vec) JIRF_GEMM_CASE(LD_PLAIN, true); else JIRF_GEMM_CASE(LD_PLAIN, false);
@@ -307,19 +352,23 @@ static void launch_tile(const GemmArgs& a, int loader, bool vec, hipStream_t s) 
 void launch_gemm(const GemmArgs& a, int loader, hipStream_t s) {
   JIRF_REQUIRE(a.B > 0 && a.M > 0 && a.K > 0 && a.P > 0, JIRF_EINVAL,
                "launch_gemm: empty problem B=%d M=%d K=%d P=%d", a.B, a.M, a.K, a.P);
-  JIRF_REQUIRE(a.Mpad % GEMM_MPAD == 0 && a.Mpad >= a.M, JIRF_EINVAL,
+  JIRF_REQUIRE(a.Mpad % 4 == 0 && a.Mpad >= a.M, JIRF_EINVAL,
                "launch_gemm: packed row length %d does not cover M=%d", a.Mpad, a.M);
   if (loader == LD_CONV3)
-    JIRF_REQUIRE(a.H * a.W == a.P && a.K == 9 * a.Cin && a.H < 65536 && a.W < 65536, JIRF_EINVAL,
+    JIRF_REQUIRE(a.H * a.W == a.P && a.K == 9 * a.Cin && a.H < 32768 && a.W < 65536, JIRF_EINVAL,
                  "launch_gemm: conv3x3 geometry H=%d W=%d P=%d K=%d Cin=%d", a.H, a.W, a.P, a.K,
                  a.Cin);
   if (a.epi == EP_UNSHUFFLE || a.epi == EP_SHUFFLE)
     JIRF_REQUIRE(a.H * a.W == a.P && (a.epi == EP_SHUFFLE || (a.H % 2 == 0 && a.W % 2 == 0)),
                  JIRF_EINVAL, "launch_gemm: (un)shuffle geometry H=%d W=%d P=%d", a.H, a.W, a.P);
+  const bool epi_ok =
+      loader == LD_GATHER ? a.epi == EP_AV_INTRA
+      : loader == LD_LN   ? a.epi == EP_STORE
+      : loader == LD_CONV3 ? (a.epi == EP_STORE || a.epi == EP_RESID || a.epi == EP_UNSHUFFLE || a.epi == EP_SHUFFLE)
+                           : (a.epi == EP_STORE || a.epi == EP_RESID || a.epi == EP_GELU_MUL);
+  JIRF_REQUIRE(epi_ok, JIRF_EINVAL, "launch_gemm: epilogue %d is not built for loader %d", a.epi, loader);
   // float4 activation loads need 16-byte aligned rows: pixel count and strides multiples of 4
   const bool vec = a.P % 4 == 0 && a.x.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x.p) & 15) == 0;
-  const long b128 = (long)((a.M + 127) / 128) * ((a.P + 127) / 128) * a.B;
-  const long b64x128 = (long)((a.M + 63) / 64) * ((a.P + 127) / 128) * a.B;
   const char* name = loader == LD_CONV3 ? "gemm_conv3x3" : loader == LD_GATHER ? "gemm_attn_v"
                      : loader == LD_LN  ? "gemm_ln_1x1" : "gemm_1x1";
   const double flops = 2.0 * a.M * (double)a.K * a.P * a.B;
@@ -327,13 +376,23 @@ void launch_gemm(const GemmArgs& a, int loader, hipStream_t s) {
   double bytes = 4.0 * a.B * (double)a.P * (kin + a.M) + 4.0 * a.K * (double)a.M * (a.wt_bs ? a.B : 1);
   if (a.epi == EP_RESID || a.epi == EP_GELU_MUL) bytes += 4.0 * a.B * (double)a.P * a.M;
   if (a.epi == EP_AV_INTRA) bytes += 4.0 * a.B * (double)a.P * a.M * 3;
-  Scope sc(name, flops, bytes, s);
-  if (a.M > 64 && b128 >= 512)
-    launch_tile<128, 128>(a, loader, vec, s);
-  else if (b64x128 >= 512)
-    launch_tile<64, 128>(a, loader, vec, s);
+  Scope sc(intern_label("%s M%d K%d P%d", name, a.M, a.K, a.P), flops, bytes, s);
+
+  // Tile choice: least padded rows first (MFMA work is wasted on padding), then the largest tile
+  // that still gives every CU at least two workgroups.
+  auto blocks = [&](int bm, int bn) {
+    return (long)((a.M + bm - 1) / bm) * ((a.P + bn - 1) / bn) * a.B;
+  };
+  auto padded = [&](int bm) { return (a.M + bm - 1) / bm * bm; };
+  const int pad128 = padded(128), pad96 = padded(96), pad64 = padded(64);
+  if (pad96 < pad128 && pad96 <= pad64 && blocks(96, 128) >= 512)
+    launch_tile<3, 1, 1, 4>(a, loader, vec, s);
+  else if (pad128 <= pad64 && blocks(128, 128) >= 512)
+    launch_tile<2, 2, 2, 2>(a, loader, vec, s);
+  else if (blocks(64, 128) >= 512)
+    launch_tile<2, 2, 1, 2>(a, loader, vec, s);
   else
-    launch_tile<64, 64>(a, loader, vec, s);
+    launch_tile<2, 2, 1, 1>(a, loader, vec, s);
 }
 
 int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad) {

@@ -598,7 +598,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
   const double tile_px = (double)tiles * tiles * ST_T * ST_T * (double)P;
   if (ipg == 1) {
     st.qg = q.p; st.qg_bs = q.bs;
-    Scope scope("hint_chan_stats", 4.0 * tile_px * B, 8.0 * B * (double)C * P, s);
+    Scope scope(intern_label("hint_chan_stats C%d P%d S%d", C, P, sh.splits), 4.0 * tile_px * B, 8.0 * B * (double)C * P, s);
     hipLaunchKernelGGL((chan_stats_kernel<true, true>), dim3(tiles * tiles, sh.splits, B), dim3(256),
                        0, s, st);
   } else {
@@ -661,7 +661,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     }
     double fl = 0.0;
     for (int i = 0; i < 4; ++i) fl += (pooled ? 6.0 : 0.0) * sh.gsz[i] * (double)sh.gsz[i] * sh.gsz[i];
-    Scope scope("hint_group_attn", fl * B, 12.0 * B * (double)C * C, s);
+    Scope scope(intern_label("hint_group_attn C%d", C), fl * B, 12.0 * B * (double)C * C, s);
     hipLaunchKernelGGL(group_attn_kernel, dim3(4, B), dim3(256), smem, s, ga);
     JIRF_HIP_CHECK(hipGetLastError());
   }

@@ -68,7 +68,7 @@ void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, 
 
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s) {
   const dim3 grid((P + 255) / 256, B), block(256);
-  Scope sc("ln_stats", 5.0 * B * (double)C * P, 4.0 * B * (double)P * (C + 2), s);
+  Scope sc(intern_label("ln_stats C%d P%d", C, P), 5.0 * B * (double)C * P, 4.0 * B * (double)P * (C + 2), s);
   hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x.p, x.bs, nullptr, nullptr, nullptr,
                      0L, mu, rstd, C, P);
   JIRF_HIP_CHECK(hipGetLastError());
@@ -165,7 +165,7 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
   const int Cout = gate ? C / 2 : C;
   const dim3 grid((unsigned)(tiles_x * tiles_y * Cout), B), block(256);
   const double px = (double)B * H * W;
-  Scope sc(gate ? "dwconv3x3_gate" : "dwconv3x3", 18.0 * px * C, 4.0 * px * (C + Cout), s);
+  Scope sc(intern_label("%s C%d H%d W%d", gate ? "dwconv3x3_gate" : "dwconv3x3", C, H, W), 18.0 * px * C, 4.0 * px * (C + Cout), s);
   if (gate)
     hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C,
                        H, W, tiles_x, tiles_y);

@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 
 namespace jirf {
 
@@ -228,6 +230,18 @@ void KernelClock::collect() {
 }
 KernelClock::~KernelClock() {
   for (auto e : pool) (void)hipEventDestroy(e);
+}
+
+const char* intern_label(const char* fmt, ...) {
+  static std::mutex mu;
+  static std::set<std::string> table;
+  char buf[160];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  std::lock_guard<std::mutex> lock(mu);
+  return table.insert(buf).first->c_str();
 }
 
 struct ScopeState {

@@ -224,7 +224,7 @@ class Net:
         check(lib().jirf_net_enable_kernel_timing(self._h, int(on)))
 
     def kernel_times(self) -> List[dict]:
-        cap = 64
+        cap = 512
         names = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()

@@ -1,0 +1,122 @@
+"""CPU tests of the oracle: golden-fixture regression, two independent restatements against each
+other, and the index/formula ops on their own.  (Parity unpinned: the fixtures come from the
+oracle itself — see tests/make_golden.py.)"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import common as oc
+from oracle import hint_oracle as ho
+from oracle.hint_numpy import _adaptive_pool, _bilinear_up, hint_forward_numpy
+from oracle.weights import make_hint_state, synthetic_images
+from tests.make_golden import HINT_SMALL, weights_digest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name,cfg", [("hint_small_48x64", HINT_SMALL), ("hint_full_32x32", None),
+                                      ("hint_small_modgain_32x48", HINT_SMALL)])
+def test_oracle_reproduces_golden(name, cfg):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = cfg or ho.default_config()
+    sd = make_hint_state(cfg, seed=int(g["seed"]), gain=0.6, mod_gain=float(g["mod_gain"]))
+    assert weights_digest(sd) == str(g["weights_sha256"]), "weight generator changed: regenerate the fixtures"
+    taps = {}
+    y1, c1 = ho.hint_forward(sd, torch.from_numpy(g["x1"]), cfg, None, tap=lambda n, t: taps.__setitem__(n, t))
+    perms = np.concatenate([taps[n].numpy() for n in taps if n.endswith(".attn.perm")])
+    assert np.array_equal(perms, g["perms1"])
+    assert np.abs(y1.numpy() - g["y1"]).max() < 2e-5
+    assert np.abs(c1.numpy() - g["cache1"]).max() < 1e-6
+    y2, c2 = ho.hint_forward(sd, torch.from_numpy(g["x2"]), cfg, torch.from_numpy(g["cache1"]))
+    assert np.abs(y2.numpy() - g["y2"]).max() < 2e-5
+    assert np.mean(np.abs(c2.numpy() - g["cache2"]) > 1e-6) < 1e-3
+
+
+TINY = dict(inp_channels=3, out_channels=3, dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1,
+            heads=[1, 1, 1, 1], ffn_expansion_factor=2.66, bias=False, ln_type="WithBias", dual_pixel_task=False)
+
+
+@pytest.mark.parametrize("ln_type,mod_gain", [("WithBias", 1.0), ("BiasFree", 1.0), ("WithBias", 3.0)])
+def test_two_restatements_agree(ln_type, mod_gain):
+    """torch-fp32 oracle vs the NumPy-float64 transcription: same channel orders, outputs within
+    fp32 noise, cold call and warm call."""
+    cfg = dict(TINY, ln_type=ln_type)
+    sd = make_hint_state(cfg, seed=2, gain=0.6, mod_gain=mod_gain)
+    x = synthetic_images(2, 16, 24, seed=4, sigma=50)
+    taps = {}
+    y, c = ho.hint_forward(sd, torch.from_numpy(x), cfg, None, tap=lambda n, t: taps.__setitem__(n, t))
+    yn, cn, orders = hint_forward_numpy(sd, x, cfg, None)
+    for name, order in orders.items():
+        assert np.array_equal(order, taps[name + ".attn.perm"].numpy()), name
+    assert np.abs(y.numpy() - yn).max() < 5e-5
+    assert np.mean(np.abs(c.numpy() - cn) > 1e-5) < 5e-3
+    y2, c2 = ho.hint_forward(sd, torch.from_numpy(x), cfg, torch.from_numpy(cn.astype(np.float32)))
+    yn2, cn2, _ = hint_forward_numpy(sd, x, cfg, cn)
+    assert np.abs(y2.numpy() - yn2).max() < 5e-5
+    assert np.mean(np.abs(c2.numpy() - cn2) > 1e-5) < 5e-3
+
+
+def test_pixel_shuffle_maps():
+    x = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    u = oc.pixel_unshuffle2(x)
+    for c in range(3):
+        for i in range(2):
+            for j in range(2):
+                assert torch.equal(u[:, 4 * c + 2 * i + j], x[:, c, i::2, j::2])
+    assert torch.equal(oc.pixel_shuffle2(u), x)
+    assert torch.equal(u, F.pixel_unshuffle(x, 2))
+    assert torch.equal(oc.pixel_shuffle2(u), F.pixel_shuffle(u, 2))
+
+
+@pytest.mark.parametrize("n_in,n_out", [(384, 192), (192, 96), (96, 384), (384, 144), (96, 36), (96, 12), (192, 72), (7, 5)])
+def test_adaptive_pool_bounds_and_values(n_in, n_out):
+    s, e = oc.adaptive_pool_bounds(n_in, n_out)
+    for i in range(n_out):     # the reference's float expressions (hint_arch.py:80-81)
+        assert s[i] == math.floor(i * n_in / n_out)
+        assert e[i] == math.ceil((i + 1) * n_in / n_out)
+        assert e[i] > s[i]
+    x = torch.randn(1, n_in, n_in, generator=torch.Generator().manual_seed(0))
+    got = oc.adaptive_avg_pool_sq(x, n_out)[0].numpy()
+    if n_in * n_out <= 96 * 36:
+        assert np.abs(got - _adaptive_pool(x[0].double().numpy(), n_out)).max() < 1e-6
+    assert np.abs(got - F.adaptive_avg_pool2d(x[None], n_out)[0, 0].numpy()).max() < 1e-5
+
+
+def test_bilinear_matches_independent_formula():
+    m = torch.randn(12, 12, generator=torch.Generator().manual_seed(1))
+    up = F.interpolate(m[None, None], size=(96, 96), mode="bilinear", align_corners=False)[0, 0]
+    assert np.abs(up.numpy() - _bilinear_up(m.double().numpy(), 96)).max() < 1e-6
+
+
+def test_layer_cache_floor_semantics():
+    sw = ho.HintSwitches()
+    att = [torch.full((1, 2, 2), 5.0), torch.full((1, 4, 4), -0.3), torch.full((1, 4, 4), 0.2), torch.full((1, 6, 6), 2.9)]
+    got = ho.layer_cache(att, 16, sw)
+    # floor(5*2/16)=0, floor(-0.3*4/16)=-1, floor(0.2*4/16)=0, floor(2.9*6/16)=1
+    assert torch.equal(got, torch.zeros(1, 16, 16))
+    assert torch.equal(ho.layer_cache(att, 16, ho.HintSwitches(floordiv="trunc")), torch.ones(1, 16, 16))
+
+
+def test_group_sizes_and_stage_plan():
+    assert ho.group_sizes(96) == [12, 24, 24, 36]
+    assert ho.group_sizes(384) == [48, 96, 96, 144]
+    plan = ho.stage_plan(ho.default_config())
+    assert [(n, k) for n, k, _, _ in plan] == [("encoder_level1", 4), ("encoder_level2", 6), ("encoder_level3", 6),
+                                               ("latent", 6), ("decoder_level3", 6), ("decoder_level2", 6),
+                                               ("decoder_level1", 4), ("refinement", 4)]
+
+
+def test_batch_coupling_is_visible():
+    """A literal B=2 call differs from two B=1 calls (batch-mean statistics), hence two batch modes."""
+    sd = make_hint_state(TINY, seed=2, gain=0.6)
+    x = torch.from_numpy(synthetic_images(2, 16, 16, seed=9, sigma=50))
+    y_c, _ = ho.hint_forward(sd, x, TINY)
+    y_p, c_p = ho.hint_forward_per_image(sd, x, TINY)
+    assert c_p.shape[0] == 2
+    assert float((y_c - y_p).abs().max()) > 1e-4
+    y0, _ = ho.hint_forward(sd, x[:1], TINY)
+    assert torch.equal(y0, y_p[:1])
