@@ -108,8 +108,10 @@ int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mp
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s);
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s);
+// gate: 0 plain, 1 gelu(dw(x1)) * dw(x2), 2 dw(x1) * x2.  wmod/wconv: ASTv2 partial convolution
+// (channel c uses weight c % wmod when c % wmod < wconv, and is copied through otherwise).
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
-                      int gate, hipStream_t s);
+                      int gate, hipStream_t s, int wmod = 0, int wconv = 0);
 
 // ---- HINT channel attention ------------------------------------------------------------------
 struct HintAttnShape {
@@ -152,6 +154,23 @@ size_t hint_attn_scratch_carve(const HintAttnShape& sh, void* base, HintAttnScra
 void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWeights& w,
                            const float* cache_in, int cache_c, float* cache_out,
                            const HintAttnScratch& sc, int* perm_out, const int* forced_perm,
+                           hipStream_t s);
+
+// ---- head-wise channel attention (ASTv2) -------------------------------------------------------
+struct HeadAttnScratch {
+  float* qk_part;  // [B][splits][C][C]
+  float* q2_part;  // [B][splits][C]
+  float* k2_part;  // [B][splits][C]
+  float* s_qk;     // [B][C][C]
+  float* rq;       // [B][C]
+  float* rk;       // [B][C]
+  float* att_t;    // [B][Kpad][Mpad] block-diagonal attention, transposed (GEMM weight layout)
+};
+int head_attn_splits(int B, int C, int P);
+size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, HeadAttnScratch* out);
+// q, k: channel slices of the dw-conv output.  Leaves the per-image attention in sc.att_t.
+void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const float* temperature,
+                           const float* ca_w, const float* ca_b, const HeadAttnScratch& sc,
                            hipStream_t s);
 
 // ---- kernel accounting -----------------------------------------------------------------------

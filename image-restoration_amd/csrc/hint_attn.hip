@@ -45,6 +45,7 @@ struct StatsArgs {
   const float* k; long k_bs;     // per-image k
   const float* qg; long qg_bs;   // gram source: q of the image (per-image mode) or batch-mean q
   int C, P, tiles, splits, chunks_per_split;
+  int head_ch;       // > 0: only tile pairs that intersect a diagonal head block of this size
   float* qk_part;    // [nb][splits][C][C]
   double* gram_part; // [nb][splits][C][C]
   double* qsum_part; // [nb][splits][C]
@@ -66,6 +67,12 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
   const int sp = blockIdx.y, b = blockIdx.z;
   const int C = a.C, P = a.P;
   const int i0 = ti * ST_T, j0 = tj * ST_T;
+  if (a.head_ch > 0) {
+    // heads touched by the row tile / by the column tile; nothing to do when they are disjoint
+    const int hi0 = i0 / a.head_ch, hi1 = (min(i0 + ST_T, C) - 1) / a.head_ch;
+    const int hj0 = j0 / a.head_ch, hj1 = (min(j0 + ST_T, C) - 1) / a.head_ch;
+    if (hi1 < hj0 || hj1 < hi0) return;
+  }
   const int c_begin = sp * a.chunks_per_split;
   const int c_end = min(c_begin + a.chunks_per_split, (P + ST_CH - 1) / ST_CH);
 
@@ -124,13 +131,13 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
         for (int s = 0; s < ST_CH / 2; ++s)
           s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], s_acc, 0, 0, 0);
       }
-      if (tj == 0 && tid < 64) {
+      if (tj == ti && tid < 64) {
         float t = 0.f;
 #pragma unroll
         for (int e = 0; e < ST_CH; ++e) t = fmaf(Qi[tid * ST_LD + e], Qi[tid * ST_LD + e], t);
         row_sq += t;
       }
-      if (ti == 0 && tid >= 64 && tid < 128) {
+      if (ti == tj && tid >= 64 && tid < 128) {
         const int r = tid - 64;
         float t = 0.f;
 #pragma unroll
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
               g_acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[u], g_acc[t][u], 0, 0, 0);
         }
       }
-      if (tj == 0 && tid >= 128 && tid < 192) {
+      if (tj == ti && tid >= 128 && tid < 192) {
         const int r = tid - 128;
         double t = 0.0;
 #pragma unroll
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
       const int col = j0 + wj * 32 + l31;
       if (row < C && col < C) out[(long)row * C + col] = s_acc[r];
     }
-    if (tj == 0 && tid < 64 && i0 + tid < C) a.q2_part[slab + i0 + tid] = row_sq;
-    if (ti == 0 && tid >= 64 && tid < 128 && j0 + tid - 64 < C) a.k2_part[slab + j0 + tid - 64] = row_sq;
+    if (tj == ti && tid < 64 && i0 + tid < C) a.q2_part[slab + i0 + tid] = row_sq;
+    if (ti == tj && tid >= 64 && tid < 128 && j0 + tid - 64 < C) a.k2_part[slab + j0 + tid - 64] = row_sq;
   }
   if constexpr (DO_GRAM) {
     double* __restrict__ out = a.gram_part + slab * C;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
           const int col = j0 + wj * 32 + u * 16 + l15;
           if (row < C && col < C) out[(long)row * C + col] = g_acc[t][u][r];
         }
-    if (tj == 0 && tid >= 128 && tid < 192 && i0 + tid - 128 < C)
+    if (tj == ti && tid >= 128 && tid < 192 && i0 + tid - 128 < C)
       a.qsum_part[slab + i0 + tid - 128] = row_sum;
   }
 }
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
     rq[(long)b * C + i] = 1.0f / sqrtf(fmaxf(q2, NORM_EPS));
     rk[(long)b * C + i] = 1.0f / sqrtf(fmaxf(k2, NORM_EPS));
   }
-  if (b % ipg != 0) return;
+  if (sim == nullptr || b % ipg != 0) return;
   const int g = b / ipg;
   const double L = (double)P;
   for (int j = tid; j < C; j += 256) {
@@ -672,6 +679,153 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     cu.att_nat = sc.att_nat; cu.pooled = pooled; cu.cache_out = cache_out;
     Scope scope("hint_cache_update", 40.0 * G * (double)C * C, 12.0 * G * (double)C * C, s);
     hipLaunchKernelGGL(cache_update_kernel, dim3((C * C + 255) / 256, G), dim3(256), 0, s, cu);
+    JIRF_HIP_CHECK(hipGetLastError());
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head-wise channel attention of ASTv2 (reference basicsr/models/archs/astv2_arch.py:158-206):
+// fixed heads of ch = C / heads channels, no regrouping, no cache.  One workgroup per (head, image):
+//   A  = (q^ k^T) * T_head          S0 = softmax_rows(A)          R = relu(A)^2 ; R = gelu(R) * R
+//   Z[o][j] = sum_i Wca[o][i] R[i][j] (+ b[o])                    (1x1 conv over the ROW axis)
+//   A'[r][c] = S0[r][c] * (1 + Z[c][r]) + Z[ch + c][r]            (scale / shift are Z's halves,
+//                                                                   transposed by the permutes)
+// ------------------------------------------------------------------------------------------------
+struct HeadAttnArgs {
+  int C, heads, ch, Mpad;
+  const float* s_qk;         // [B][C][C]
+  const float* rq;           // [B][C]
+  const float* rk;           // [B][C]
+  const float* temperature;  // [heads]
+  const float* ca_w;         // [2ch][ch]
+  const float* ca_b;         // [2ch] or null
+  float* att_t;              // [B][Kpad][Mpad]
+};
+
+__global__ __launch_bounds__(256) void head_attn_kernel(const HeadAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ha_smem[];
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int C = a.C, c = a.ch, off = h * c, ld = c + 1;
+  float* S0 = reinterpret_cast<float*>(ha_smem);  // [c][ld] softmax branch
+  float* R = S0 + c * ld;                         // [c][ld] sparse branch
+  float* Z = R + c * ld;                          // [2c][ld]
+  const float temp = a.temperature[h];
+  const float* __restrict__ S = a.s_qk + (long)b * C * C;
+  for (int e = tid; e < c * c; e += 256) {
+    const int r = e / c, s = e - r * c;
+    const float v = S[(long)(off + r) * C + off + s] * a.rq[(long)b * C + off + r] *
+                    a.rk[(long)b * C + off + s] * temp;
+    S0[r * ld + s] = v;
+    const float p = fmaxf(v, 0.f);
+    const float p2 = p * p;
+    R[r * ld + s] = gelu_erf_a(p2) * p2;
+  }
+  __syncthreads();
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < c; r += 4) {
+      float m = -INFINITY;
+      for (int s = lane; s < c; s += 64) m = fmaxf(m, S0[r * ld + s]);
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float sum = 0.f;
+      for (int s = lane; s < c; s += 64) {
+        const float e = expf(S0[r * ld + s] - m);
+        S0[r * ld + s] = e;
+        sum += e;
+      }
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float inv = 1.0f / sum;
+      for (int s = lane; s < c; s += 64) S0[r * ld + s] *= inv;
+    }
+  }
+  for (int e = tid; e < 2 * c * c; e += 256) {
+    const int o = e / c, j = e - o * c;
+    float z = a.ca_b ? a.ca_b[o] : 0.f;
+    const float* __restrict__ w = a.ca_w + (long)o * c;
+    for (int i = 0; i < c; ++i) z = fmaf(w[i], R[i * ld + j], z);
+    Z[o * ld + j] = z;
+  }
+  __syncthreads();
+  const int kpad = ((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD;
+  float* __restrict__ att_t = a.att_t + (long)b * kpad * a.Mpad;
+  // rows [off, off + c) of the transposed image are this head's (the last head also owns the
+  // padding rows); everything outside the diagonal block must read as zero in the GEMM
+  const int row_end = h == a.heads - 1 ? kpad : off + c;
+  for (int e = tid; e < (row_end - off) * a.Mpad; e += 256) {
+    const int kr = off + e / a.Mpad, m = e % a.Mpad;
+    float v = 0.f;
+    if (kr < off + c && m >= off && m < off + c) {
+      const int col = kr - off, r = m - off;   // att_t[k = col][m = row] = A'[row][col]
+      v = S0[r * ld + col] * (1.0f + Z[col * ld + r]) + Z[(c + col) * ld + r];
+    }
+    att_t[(long)kr * a.Mpad + m] = v;
+  }
+}
+
+size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, HeadAttnScratch* o) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void* p = base ? static_cast<unsigned char*>(base) + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  const size_t kpad = ((size_t)C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  const size_t mpad = ((size_t)C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+  o->qk_part = static_cast<float*>(take((size_t)B * splits * C * C * 4));
+  o->q2_part = static_cast<float*>(take((size_t)B * splits * C * 4));
+  o->k2_part = static_cast<float*>(take((size_t)B * splits * C * 4));
+  o->s_qk = static_cast<float*>(take((size_t)B * C * C * 4));
+  o->rq = static_cast<float*>(take((size_t)B * C * 4));
+  o->rk = static_cast<float*>(take((size_t)B * C * 4));
+  o->att_t = static_cast<float*>(take((size_t)B * kpad * mpad * 4));
+  return off;
+}
+
+int head_attn_splits(int B, int C, int P) { return hint_attn_shape(B, C, P, JIRF_BATCH_PER_IMAGE).splits; }
+
+void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const float* temperature,
+                           const float* ca_w, const float* ca_b, const HeadAttnScratch& sc,
+                           hipStream_t s) {
+  JIRF_REQUIRE(heads > 0 && C % heads == 0, JIRF_EINVAL, "head attention: C=%d is not divisible by heads=%d", C, heads);
+  const int ch = C / heads;
+  const size_t smem = (size_t)4 * ch * (ch + 1) * 4;
+  JIRF_REQUIRE(smem <= 160 * 1024, JIRF_EINVAL, "head attention: %d channels per head do not fit LDS", ch);
+  const int splits = head_attn_splits(B, C, P);
+  const int tiles = (C + ST_T - 1) / ST_T;
+  const int chunks = (P + ST_CH - 1) / ST_CH;
+  StatsArgs st{};
+  st.q = q.p; st.q_bs = q.bs; st.k = k.p; st.k_bs = k.bs;
+  st.C = C; st.P = P; st.tiles = tiles; st.splits = splits;
+  st.chunks_per_split = (chunks + splits - 1) / splits;
+  st.head_ch = ch;
+  st.qk_part = sc.qk_part; st.q2_part = sc.q2_part; st.k2_part = sc.k2_part;
+  {
+    Scope scope(intern_label("head_chan_stats C%d P%d S%d", C, P, splits), 2.0 * C * (double)ch * P * B,
+                8.0 * B * (double)C * P, s);
+    hipLaunchKernelGGL((chan_stats_kernel<true, false>), dim3(tiles * tiles, splits, B), dim3(256), 0, s, st);
+    JIRF_HIP_CHECK(hipGetLastError());
+  }
+  {
+    Scope scope("head_reduce_rows", 1.0 * C * (double)C * splits * B, 4.0 * C * (double)C * splits * B, s);
+    hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), 0, s, sc.qk_part, nullptr, nullptr,
+                       sc.q2_part, sc.k2_part, sc.s_qk, sc.rq, sc.rk, nullptr, C, P, splits, 1);
+    JIRF_HIP_CHECK(hipGetLastError());
+  }
+  {
+    HeadAttnArgs ha{};
+    ha.C = C; ha.heads = heads; ha.ch = ch;
+    ha.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+    ha.s_qk = sc.s_qk; ha.rq = sc.rq; ha.rk = sc.rk; ha.temperature = temperature;
+    ha.ca_w = ca_w; ha.ca_b = ca_b; ha.att_t = sc.att_t;
+    static bool attr_set = false;
+    if (!attr_set) {
+      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_attn_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    Scope scope(intern_label("head_attn C%d ch%d", C, ch), 4.0 * ch * (double)ch * ch * heads * B,
+                8.0 * B * (double)C * C, s);
+    hipLaunchKernelGGL(head_attn_kernel, dim3(heads, B), dim3(256), smem, s, ha);
     JIRF_HIP_CHECK(hipGetLastError());
   }
 }

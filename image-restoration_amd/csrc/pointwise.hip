@@ -75,19 +75,26 @@ void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStrea
 }
 
 // ---- depthwise 3x3, zero padding 1 ---------------------------------------------------------------
-// A workgroup owns a TH x TW output tile of one channel plane (two planes when the gate is
+// A workgroup owns a TH x TW output tile of one channel plane (two planes when a gate is
 // fused), staged with its one-pixel halo in LDS; each lane then produces 4 adjacent pixels of a
-// row from 3 x 6 LDS values.  GATE: out[c] = gelu(dw(x[c])) * dw(x[c + Ch]) for c < Ch.
+// row from 3 x 6 LDS values.
+//   MODE 0  y[c] = dw(x[c])
+//   MODE 1  y[c] = gelu(dw(x[c])) * dw(x[c + Ch])   for c < Ch = C/2   (HINT GDFN)
+//   MODE 2  y[c] = dw(x[c]) * x[c + Ch]              (ASTv2 FeedForward: second half un-convolved)
+// wmod > 0 (MODE 0 only) selects the "partial convolution" of ASTv2: channel c uses weight
+// c % wmod when c % wmod < wconv and is copied through otherwise.
 constexpr int DW_TH = 16, DW_TW = 64;
 
-template <bool GATE>
+template <int MODE>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, long x_bs,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, long y_bs, int C,
-                                                        int H, int W, int tiles_x, int tiles_y) {
+                                                        int H, int W, int tiles_x, int tiles_y,
+                                                        int wmod, int wconv) {
   constexpr int LW = DW_TW + 2 + 2;  // halo + pad so rows are 68 floats (odd multiple of 4 banks)
-  __shared__ float tile[GATE ? 2 : 1][(DW_TH + 2) * LW];
+  constexpr int NP = MODE == 0 ? 1 : 2;
+  __shared__ float tile[NP][(DW_TH + 2) * LW];
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int tx = t % tiles_x;
@@ -97,10 +104,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   const int b = blockIdx.y;
   const int x0 = tx * DW_TW, y0 = ty * DW_TH;
   const long P = (long)H * W;
-  const int Cout = GATE ? C / 2 : C;
+  const int Cout = MODE == 0 ? C : C / 2;
 
 #pragma unroll
-  for (int g = 0; g < (GATE ? 2 : 1); ++g) {
+  for (int g = 0; g < NP; ++g) {
     const float* __restrict__ plane = x + (long)b * x_bs + (long)(c + g * Cout) * P;
     for (int i = tid; i < (DW_TH + 2) * (DW_TW + 2); i += 256) {
       const int r = i / (DW_TW + 2), q = i - r * (DW_TW + 2);
@@ -115,14 +122,25 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   const int q = (tid & 15) * 4;    // 0..60 output col in tile
   const int oy = y0 + r, ox = x0 + q;
   if (oy >= H || ox >= W) return;
-  float res[GATE ? 2 : 1][4];
+  float res[NP][4];
 #pragma unroll
-  for (int g = 0; g < (GATE ? 2 : 1); ++g) {
+  for (int g = 0; g < NP; ++g) {
     const int ch = c + g * Cout;
+    int wch = ch;
+    bool through = MODE == 2 && g == 1;
+    if (MODE == 0 && wmod > 0) {
+      wch = ch % wmod;
+      through = wch >= wconv;
+    }
+    if (through) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) res[g][j] = tile[g][(r + 1) * LW + q + 1 + j];
+      continue;
+    }
     float k[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) k[i] = w[ch * 9 + i];
-    const float bb = bias ? bias[ch] : 0.f;
+    for (int i = 0; i < 9; ++i) k[i] = w[wch * 9 + i];
+    const float bb = bias ? bias[wch] : 0.f;
     float acc[4] = {bb, bb, bb, bb};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -142,8 +160,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   float out[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if constexpr (GATE)
-      out[j] = gelu_erf_pw(res[0][j]) * res[GATE ? 1 : 0][j];
+    if constexpr (MODE == 1)
+      out[j] = gelu_erf_pw(res[0][j]) * res[NP - 1][j];
+    else if constexpr (MODE == 2)
+      out[j] = res[0][j] * res[NP - 1][j];
     else
       out[j] = res[0][j];
   }
@@ -159,19 +179,26 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 }
 
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
-                      int gate, hipStream_t s) {
-  JIRF_REQUIRE(!gate || C % 2 == 0, JIRF_EINVAL, "dwconv3x3: gated form needs an even channel count");
+                      int gate, hipStream_t s, int wmod, int wconv) {
+  JIRF_REQUIRE(gate >= 0 && gate <= 2, JIRF_EINVAL, "dwconv3x3: mode %d", gate);
+  JIRF_REQUIRE(!gate || C % 2 == 0, JIRF_EINVAL, "dwconv3x3: gated forms need an even channel count");
+  JIRF_REQUIRE(wmod == 0 || (gate == 0 && wconv > 0 && wconv <= wmod && C % wmod == 0), JIRF_EINVAL,
+               "dwconv3x3: bad partial-convolution pattern %d/%d for C=%d", wconv, wmod, C);
   const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
   const int Cout = gate ? C / 2 : C;
   const dim3 grid((unsigned)(tiles_x * tiles_y * Cout), B), block(256);
   const double px = (double)B * H * W;
-  Scope sc(intern_label("%s C%d H%d W%d", gate ? "dwconv3x3_gate" : "dwconv3x3", C, H, W), 18.0 * px * C, 4.0 * px * (C + Cout), s);
-  if (gate)
-    hipLaunchKernelGGL(dwconv3x3_kernel<true>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C,
-                       H, W, tiles_x, tiles_y);
+  const char* nm = wmod ? "dwconv3x3_partial" : gate == 1 ? "dwconv3x3_gate" : gate == 2 ? "dwconv3x3_mul" : "dwconv3x3";
+  Scope sc(intern_label("%s C%d H%d W%d", nm, C, H, W), 18.0 * px * (gate == 2 ? C / 2 : C), 4.0 * px * (C + Cout), s);
+  if (gate == 1)
+    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
+                       tiles_x, tiles_y, 0, 0);
+  else if (gate == 2)
+    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
+                       tiles_x, tiles_y, 0, 0);
   else
-    hipLaunchKernelGGL(dwconv3x3_kernel<false>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C,
-                       H, W, tiles_x, tiles_y);
+    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
+                       tiles_x, tiles_y, wmod, wconv);
   JIRF_HIP_CHECK(hipGetLastError());
 }
 

@@ -113,3 +113,60 @@ def synthetic_images(b: int, h: int, w: int, seed: int = 0, sigma: float | None 
     if sigma is not None:
         x = (x + rng.normal(0.0, sigma / 255.0, x.shape)).astype(np.float32)
     return x
+
+
+def make_astv2_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """ASTv2 state dict (astv2_arch.py:79-100,136-156,303-436 constructors)."""
+    from .astv2_oracle import default_config, stage_plan
+    cfg = cfg or default_config()
+    g = _Gen(seed, gain)
+    dim, bias = cfg["dim"], cfg.get("bias", False)
+    with_bias_ln = cfg.get("ln_type", "WithBias") != "BiasFree"
+    ffn = cfg["ffn_expansion_factor"]
+    heads = cfg["heads"]
+    cin, cout = cfg.get("inp_channels", 3), cfg.get("out_channels", 3)
+
+    def conv(key, co, ci, k, b):
+        g.kernel(key + ".weight", (co, ci, k, k))
+        if b:
+            g.vec(key + ".bias", co, 0.0, 0.05)
+
+    def ln(key, c):
+        g.vec(key + ".body.weight", c, 1.0, 0.1)
+        if with_bias_ln:
+            g.vec(key + ".body.bias", c, 0.0, 0.1)
+
+    for name, n, mult, hi, is_att in stage_plan(cfg):
+        c = dim * mult
+        for i in range(n):
+            pre = f"{name}.{i}"
+            if is_att:
+                ln(pre + ".norm1", c)
+                a = pre + ".attn"
+                ch = c // heads[hi]
+                g.uniform(a + ".temperature", (heads[hi], 1, 1), 0.5, 2.0)
+                conv(a + ".qkv", 3 * c, c, 1, bias)
+                g.kernel(a + ".qkv_dwconv.weight", (3 * c, 1, 3, 3))
+                if bias:
+                    g.vec(a + ".qkv_dwconv.bias", 3 * c, 0.0, 0.05)
+                conv(a + ".project_out", c, c, 1, bias)
+                conv(a + ".att_ca", 2 * ch, ch, 1, bias)
+            ln(pre + ".norm2", c)
+            f = pre + ".ffn"
+            h = int(c * ffn)
+            g.kernel(f + ".partial_conv3.weight", (c // 24, 1, 3, 3))
+            conv(f + ".project_in", 2 * h, c, 1, bias)
+            g.kernel(f + ".dwconv.weight", (h, 1, 3, 3))
+            if bias:
+                g.vec(f + ".dwconv.bias", h, 0.0, 0.05)
+            conv(f + ".project_out", c, h, 1, bias)
+    g.kernel("patch_embed.proj.weight", (dim, cin, 3, 3))
+    g.kernel("down1_2.body.0.weight", (dim // 2, dim, 3, 3))
+    g.kernel("down2_3.body.0.weight", (dim, 2 * dim, 3, 3))
+    g.kernel("up3_2.body.0.weight", (8 * dim, 4 * dim, 3, 3))
+    g.kernel("up2_1.body.0.weight", (4 * dim, 2 * dim, 3, 3))
+    conv("reduce_chan_level2", 2 * dim, 4 * dim, 1, bias)
+    if cfg.get("dual_pixel_task", False):
+        conv("skip_conv", 2 * dim, dim, 1, bias)
+    conv("output", cout, 2 * dim, 3, bias)
+    return g.sd

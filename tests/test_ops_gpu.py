@@ -96,16 +96,20 @@ def test_pixel_shuffle_bit_exact():
         assert np.array_equal(y.cpu().numpy(), ref.numpy())
 
 
-@pytest.mark.parametrize("gate", [0, 1])
+@pytest.mark.parametrize("gate", [0, 1, 2])
 @pytest.mark.parametrize("B,C,H,W,bias", [(1, 254, 40, 56, False), (2, 30, 17, 70, True), (1, 144, 64, 64, False),
                                           (1, 6, 5, 3, True)])
 def test_dwconv3x3(gate, B, C, H, W, bias):
     x, w = rnd(B, C, H, W), rnd(C, 1, 3, 3, scale=1 / 3)
     b = rnd(C) if bias else None
     ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None if b is None else torch.from_numpy(b), padding=1, groups=C)
-    if gate:
+    if gate == 1:
         x1, x2 = ref.chunk(2, dim=1)
         ref = oc.gelu(x1) * x2
+    elif gate == 2:     # ASTv2 FeedForward: only the first half is convolved
+        h = C // 2
+        bb = None if b is None else torch.from_numpy(b[:h])
+        ref = F.conv2d(torch.from_numpy(x[:, :h]), torch.from_numpy(w[:h]), bb, padding=1, groups=h) * torch.from_numpy(x[:, h:])
     y = torch.empty(ref.shape, device="cuda")
     xd, wd = dev(x), dev(w)
     bd = None if b is None else dev(b)
