@@ -75,6 +75,8 @@ jirf_net* jirf_net_create(const char* arch, const char* cfg_json, int device) {
       net = make_hint_net(cfg);
     } else if (!std::strcmp(arch, "ASTv2")) {
       net = make_astv2_net(cfg);
+    } else if (!std::strcmp(arch, "AST")) {
+      net = make_ast_net(cfg);
     } else {
       // define_network raises ValueError("<type> is not found.") (archs/__init__.py:39-40)
       set_error("%s is not found.", arch);

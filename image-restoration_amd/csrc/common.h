@@ -60,7 +60,8 @@ enum GemmLoader : int {
   LD_PLAIN = 0,   // X[b][k][p]
   LD_GATHER = 1,  // X[b][kidx[g][k]][p]
   LD_LN = 2,      // (X[b][k][p] - mu[b][p]) * rstd[b][p] * lnw[k] + lnb[k]
-  LD_CONV3 = 3,   // implicit 3x3: k = tap * Cin + c, X[b][c][y+dy][x+dx], zero padded
+  LD_CONV3 = 3,   // implicit k x k conv: k = tap * Cin + c, X[b][c][y*stride-pad+ky][x*stride-pad+kx],
+                  // zero padded (3x3 s1 p1 and 4x4 s2 p1 are the shapes the networks use)
 };
 
 enum GemmEpi : int {
@@ -69,7 +70,9 @@ enum GemmEpi : int {
   EP_GELU_MUL = 2,   // y = gelu(acc + bias) * AUX
   EP_AV_INTRA = 3,   // y = acc; y2 = acc + q[perm[o]] * rq[perm[o]] + k[perm[o]] * rk[perm[o]]
   EP_UNSHUFFLE = 4,  // conv3x3 then pixel-unshuffle(2)
-  EP_SHUFFLE = 5,    // conv3x3 then pixel-shuffle(2)
+  EP_SHUFFLE = 5,    // then pixel-shuffle(2) (also the store of a 2x2 stride-2 transposed conv)
+  EP_GELU = 6,       // y = gelu(acc + bias)
+  EP_LEAKY = 7,      // y = leaky_relu(acc + bias, 0.01)
 };
 
 struct GemmArgs {
@@ -89,7 +92,11 @@ struct GemmArgs {
   const float* lnw;      // LD_LN: [K]
   const float* lnb;      // LD_LN: [K] or null (BiasFree: mu is also ignored)
   int ln_center;         // LD_LN: subtract mu (WithBias) or not (BiasFree)
-  int H, W, Cin;         // LD_CONV3 geometry
+  int H, W, Cin;         // LD_CONV3 geometry: OUTPUT height/width (H * W == P) and input channels
+  int ks, stride, pad;   // LD_CONV3: kernel edge, stride, zero padding (0 0 0 means 3 1 1)
+  int Hin, Win;          // LD_CONV3: input plane size (0 0 means H W)
+  TV x2;                 // LD_PLAIN: rows k < k_split are read from x2 instead of x
+  int k_split;
   // epilogue extras
   int epi;
   TV r;                  // EP_RESID residual / EP_GELU_MUL aux
@@ -103,12 +110,13 @@ void launch_gemm(const GemmArgs& a, int loader, hipStream_t s);
 // host-side packers (return Kpad; out is resized to Kpad * Mpad)
 int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad);
 int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad);
+int pack_wt_conv(const float* w, int M, int Cin, int ks, std::vector<float>& out, int* Mpad);
 
 // ---- memory-bound kernels -------------------------------------------------------------------
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s);
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s);
-// gate: 0 plain, 1 gelu(dw(x1)) * dw(x2), 2 dw(x1) * x2.  wmod/wconv: ASTv2 partial convolution
+// gate: 0 plain, 1 gelu(dw(x1)) * dw(x2), 2 dw(x1) * x2, 3 gelu(dw(x1)) * x2.  wmod/wconv: ASTv2 partial convolution
 // (channel c uses weight c % wmod when c % wmod < wconv, and is copied through otherwise).
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
                       int gate, hipStream_t s, int wmod = 0, int wconv = 0);
@@ -172,6 +180,20 @@ size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, Head
 void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const float* temperature,
                            const float* ca_w, const float* ca_b, const HeadAttnScratch& sc,
                            hipStream_t s);
+
+// ---- 8x8 window attention (AST) ---------------------------------------------------------------
+struct WinAttnArgs {
+  int B, C, H, W, heads;     // head_dim = C / heads must be 32, window 8 x 8
+  int shift;                 // 0 or 4: cyclic shift of the window grid (and the shift mask)
+  int coupled;               // 0: the reference's K (window, head) remap runs per image (B = 1 calls);
+                             // 1: over the whole batch (a literal B > 1 call)
+  TV q, k, v;                // planar [C][H*W] slices
+  TV out;                    // planar [C][H*W]
+  const float* table;        // relative_position_bias_table [225][heads]
+  float scale;               // head_dim^-0.5
+  float w_softmax, w_relu2;  // softmax([w0, w1]) mixing weights
+};
+void launch_window_attention(const WinAttnArgs& a, hipStream_t s);
 
 // ---- kernel accounting -----------------------------------------------------------------------
 struct KernelClock;

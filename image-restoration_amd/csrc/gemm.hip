@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
       for (int j = 0; j < 4; ++j) {
         const int p = n0 + x_col[i] + j;
         const int yy = p / a.W;
-        cv_yx[i][j] = p < P ? ((yy << 16) | (p - yy * a.W)) : -1;
+        // top-left input coordinate of the output pixel, biased by 8 so it packs unsigned
+        cv_yx[i][j] = p < P ? (((yy * a.stride - a.pad + 8) << 16) | ((p - yy * a.W) * a.stride - a.pad + 8)) : -1;
       }
   }
   const int* __restrict__ kidx = nullptr;
@@ -117,22 +118,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
     if constexpr (LOADER == LD_CONV3) {
       const int tap = k / a.Cin;
       const int c = k - tap * a.Cin;
-      const int t3 = tap / 3;
-      const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
-      const float* __restrict__ plane = xb + (long)c * P;
+      const int ky = tap / a.ks;
+      const int dy = ky - 8, dx = tap - ky * a.ks - 8;
+      const float* __restrict__ plane = xb + (long)c * a.Hin * a.Win;
       float r[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int yx = cv_yx[i][j];
         const int yy = (yx >> 16) + dy, xx = (yx & 0xffff) + dx;
-        const bool ok = yx >= 0 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        r[j] = ok ? plane[yy * a.W + xx] : 0.f;
+        const bool ok = yx >= 0 && yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win;
+        r[j] = ok ? plane[yy * a.Win + xx] : 0.f;
       }
       return make_float4(r[0], r[1], r[2], r[3]);
     } else {
       int row = k;
       if constexpr (LOADER == LD_GATHER) row = kidx[k];
       const float* __restrict__ src = xb + (long)row * P + p;
+      if constexpr (LOADER == LD_PLAIN) {
+        if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)row * P + p;
+      }
       if constexpr (VEC) {
         if (p < P) v = *reinterpret_cast<const float4*>(src);
       } else {
@@ -288,6 +292,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
             yb[(long)row * P + col] = v + aux[r];
           } else if constexpr (EPI == EP_GELU_MUL) {
             yb[(long)row * P + col] = gelu_erf(v) * aux[r];
+          } else if constexpr (EPI == EP_GELU) {
+            yb[(long)row * P + col] = gelu_erf(v);
+          } else if constexpr (EPI == EP_LEAKY) {
+            yb[(long)row * P + col] = v > 0.f ? v : 0.01f * v;
           } else if constexpr (EPI == EP_AV_INTRA) {
             yb[(long)row * P + col] = v;
             a.y2.p[(long)b * a.y2.bs + (long)row * P + col] = v + aux[r];
@@ -313,10 +321,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
     if (epi == EP_UNSHUFFLE) run_epilogue(std::integral_constant<int, EP_UNSHUFFLE>{});
     else if (epi == EP_SHUFFLE) run_epilogue(std::integral_constant<int, EP_SHUFFLE>{});
     else if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
+    else if (epi == EP_LEAKY) run_epilogue(std::integral_constant<int, EP_LEAKY>{});
     else run_epilogue(std::integral_constant<int, EP_STORE>{});
   } else {
     if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
     else if (epi == EP_GELU_MUL) run_epilogue(std::integral_constant<int, EP_GELU_MUL>{});
+    else if (epi == EP_GELU) run_epilogue(std::integral_constant<int, EP_GELU>{});
+    else if (epi == EP_SHUFFLE) run_epilogue(std::integral_constant<int, EP_SHUFFLE>{});
     else run_epilogue(std::integral_constant<int, EP_STORE>{});
   }
 }
@@ -349,30 +360,42 @@ static void launch_tile(const GemmArgs& a, int loader, bool vec, hipStream_t s) 
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
-void launch_gemm(const GemmArgs& a, int loader, hipStream_t s) {
+void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
+  GemmArgs a = a_in;
+  if (loader == LD_CONV3) {
+    if (a.ks == 0) { a.ks = 3; a.stride = 1; a.pad = 1; }
+    if (a.Hin == 0) { a.Hin = a.H; a.Win = a.W; }
+  }
   JIRF_REQUIRE(a.B > 0 && a.M > 0 && a.K > 0 && a.P > 0, JIRF_EINVAL,
                "launch_gemm: empty problem B=%d M=%d K=%d P=%d", a.B, a.M, a.K, a.P);
   JIRF_REQUIRE(a.Mpad % 4 == 0 && a.Mpad >= a.M, JIRF_EINVAL,
                "launch_gemm: packed row length %d does not cover M=%d", a.Mpad, a.M);
   if (loader == LD_CONV3)
-    JIRF_REQUIRE(a.H * a.W == a.P && a.K == 9 * a.Cin && a.H < 32768 && a.W < 65536, JIRF_EINVAL,
-                 "launch_gemm: conv3x3 geometry H=%d W=%d P=%d K=%d Cin=%d", a.H, a.W, a.P, a.K,
-                 a.Cin);
+    JIRF_REQUIRE(a.H * a.W == a.P && a.K == a.ks * a.ks * a.Cin && a.Hin < 16384 && a.Win < 32768 &&
+                     a.ks >= 1 && a.ks <= 7 && a.stride >= 1 && a.pad >= 0 && a.pad <= 7 &&
+                     (a.Hin + 2 * a.pad - a.ks) / a.stride + 1 == a.H && (a.Win + 2 * a.pad - a.ks) / a.stride + 1 == a.W,
+                 JIRF_EINVAL, "launch_gemm: conv geometry out %dx%d in %dx%d k%d s%d p%d K=%d Cin=%d", a.H, a.W,
+                 a.Hin, a.Win, a.ks, a.stride, a.pad, a.K, a.Cin);
   if (a.epi == EP_UNSHUFFLE || a.epi == EP_SHUFFLE)
     JIRF_REQUIRE(a.H * a.W == a.P && (a.epi == EP_SHUFFLE || (a.H % 2 == 0 && a.W % 2 == 0)),
                  JIRF_EINVAL, "launch_gemm: (un)shuffle geometry H=%d W=%d P=%d", a.H, a.W, a.P);
   const bool epi_ok =
       loader == LD_GATHER ? a.epi == EP_AV_INTRA
       : loader == LD_LN   ? a.epi == EP_STORE
-      : loader == LD_CONV3 ? (a.epi == EP_STORE || a.epi == EP_RESID || a.epi == EP_UNSHUFFLE || a.epi == EP_SHUFFLE)
-                           : (a.epi == EP_STORE || a.epi == EP_RESID || a.epi == EP_GELU_MUL);
+      : loader == LD_CONV3 ? (a.epi == EP_STORE || a.epi == EP_RESID || a.epi == EP_UNSHUFFLE || a.epi == EP_SHUFFLE ||
+                              a.epi == EP_LEAKY)
+                           : (a.epi == EP_STORE || a.epi == EP_RESID || a.epi == EP_GELU_MUL || a.epi == EP_GELU ||
+                              a.epi == EP_SHUFFLE);
+  if (a.k_split > 0)
+    JIRF_REQUIRE(loader == LD_PLAIN && a.x2.p && a.k_split <= a.K, JIRF_EINVAL, "launch_gemm: bad split source");
   JIRF_REQUIRE(epi_ok, JIRF_EINVAL, "launch_gemm: epilogue %d is not built for loader %d", a.epi, loader);
   // float4 activation loads need 16-byte aligned rows: pixel count and strides multiples of 4
-  const bool vec = a.P % 4 == 0 && a.x.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x.p) & 15) == 0;
+  const bool vec = a.P % 4 == 0 && a.x.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x.p) & 15) == 0 &&
+                   (a.k_split == 0 || (a.x2.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x2.p) & 15) == 0));
   const char* name = loader == LD_CONV3 ? "gemm_conv3x3" : loader == LD_GATHER ? "gemm_attn_v"
                      : loader == LD_LN  ? "gemm_ln_1x1" : "gemm_1x1";
   const double flops = 2.0 * a.M * (double)a.K * a.P * a.B;
-  const double kin = loader == LD_CONV3 ? a.Cin : a.K;
+  const double kin = loader == LD_CONV3 ? (double)a.Cin * a.Hin * a.Win / a.P : a.K;
   double bytes = 4.0 * a.B * (double)a.P * (kin + a.M) + 4.0 * a.K * (double)a.M * (a.wt_bs ? a.B : 1);
   if (a.epi == EP_RESID || a.epi == EP_GELU_MUL) bytes += 4.0 * a.B * (double)a.P * a.M;
   if (a.epi == EP_AV_INTRA) bytes += 4.0 * a.B * (double)a.P * a.M * 3;
@@ -405,18 +428,22 @@ int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad
   return kp;
 }
 
-// w [M][Cin][3][3] -> Wt[(tap * Cin + c)][o]
-int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad) {
-  const int K = 9 * Cin;
+// w [M][Cin][ks][ks] -> Wt[(tap * Cin + c)][o], tap = ky * ks + kx
+int pack_wt_conv(const float* w, int M, int Cin, int ks, std::vector<float>& out, int* Mpad) {
+  const int taps = ks * ks, K = taps * Cin;
   const int mp = (M + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
   const int kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
   out.assign((size_t)kp * mp, 0.f);
   for (int o = 0; o < M; ++o)
     for (int c = 0; c < Cin; ++c)
-      for (int t = 0; t < 9; ++t)
-        out[(size_t)(t * Cin + c) * mp + o] = w[((size_t)o * Cin + c) * 9 + t];
+      for (int t = 0; t < taps; ++t)
+        out[(size_t)(t * Cin + c) * mp + o] = w[((size_t)o * Cin + c) * taps + t];
   *Mpad = mp;
   return kp;
+}
+
+int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad) {
+  return pack_wt_conv(w, M, Cin, 3, out, Mpad);
 }
 
 }  // namespace jirf

@@ -81,6 +81,7 @@ void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStrea
 //   MODE 0  y[c] = dw(x[c])
 //   MODE 1  y[c] = gelu(dw(x[c])) * dw(x[c + Ch])   for c < Ch = C/2   (HINT GDFN)
 //   MODE 2  y[c] = dw(x[c]) * x[c + Ch]              (ASTv2 FeedForward: second half un-convolved)
+//   MODE 3  y[c] = gelu(dw(x[c])) * x[c + Ch]        (AST FRFN gate)
 // wmod > 0 (MODE 0 only) selects the "partial convolution" of ASTv2: channel c uses weight
 // c % wmod when c % wmod < wconv and is copied through otherwise.
 constexpr int DW_TH = 16, DW_TW = 64;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   for (int g = 0; g < NP; ++g) {
     const int ch = c + g * Cout;
     int wch = ch;
-    bool through = MODE == 2 && g == 1;
+    bool through = (MODE == 2 || MODE == 3) && g == 1;
     if (MODE == 0 && wmod > 0) {
       wch = ch % wmod;
       through = wch >= wconv;
@@ -164,6 +165,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
       out[j] = gelu_erf_pw(res[0][j]) * res[NP - 1][j];
     else if constexpr (MODE == 2)
       out[j] = res[0][j] * res[NP - 1][j];
+    else if constexpr (MODE == 3)
+      out[j] = gelu_erf_pw(res[0][j]) * res[NP - 1][j];
     else
       out[j] = res[0][j];
   }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
                       int gate, hipStream_t s, int wmod, int wconv) {
-  JIRF_REQUIRE(gate >= 0 && gate <= 2, JIRF_EINVAL, "dwconv3x3: mode %d", gate);
+  JIRF_REQUIRE(gate >= 0 && gate <= 3, JIRF_EINVAL, "dwconv3x3: mode %d", gate);
   JIRF_REQUIRE(!gate || C % 2 == 0, JIRF_EINVAL, "dwconv3x3: gated forms need an even channel count");
   JIRF_REQUIRE(wmod == 0 || (gate == 0 && wconv > 0 && wconv <= wmod && C % wmod == 0), JIRF_EINVAL,
                "dwconv3x3: bad partial-convolution pattern %d/%d for C=%d", wconv, wmod, C);
@@ -188,13 +191,17 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
   const int Cout = gate ? C / 2 : C;
   const dim3 grid((unsigned)(tiles_x * tiles_y * Cout), B), block(256);
   const double px = (double)B * H * W;
-  const char* nm = wmod ? "dwconv3x3_partial" : gate == 1 ? "dwconv3x3_gate" : gate == 2 ? "dwconv3x3_mul" : "dwconv3x3";
-  Scope sc(intern_label("%s C%d H%d W%d", nm, C, H, W), 18.0 * px * (gate == 2 ? C / 2 : C), 4.0 * px * (C + Cout), s);
+  const char* nm = wmod ? "dwconv3x3_partial" : gate == 1 ? "dwconv3x3_gate" : gate == 2 ? "dwconv3x3_mul"
+                   : gate == 3 ? "dwconv3x3_gelu_mul" : "dwconv3x3";
+  Scope sc(intern_label("%s C%d H%d W%d", nm, C, H, W), 18.0 * px * (gate >= 2 ? C / 2 : C), 4.0 * px * (C + Cout), s);
   if (gate == 1)
     hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
                        tiles_x, tiles_y, 0, 0);
   else if (gate == 2)
     hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
+                       tiles_x, tiles_y, 0, 0);
+  else if (gate == 3)
+    hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
                        tiles_x, tiles_y, 0, 0);
   else
     hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,

@@ -131,6 +131,7 @@ struct Net {
 
 std::unique_ptr<Net> make_hint_net(const Config& cfg);
 std::unique_ptr<Net> make_astv2_net(const Config& cfg);
+std::unique_ptr<Net> make_ast_net(const Config& cfg);
 
 // Uploads a host vector into a weight pool that lives as long as the net.
 struct WeightPool {
@@ -146,5 +147,6 @@ struct PackedW {
 };
 PackedW pack_upload_1x1(WeightPool& pool, const float* w, const float* bias, int M, int K);
 PackedW pack_upload_3x3(WeightPool& pool, const float* w, const float* bias, int M, int Cin);
+PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, int M, int Cin, int ks);
 
 }  // namespace jirf

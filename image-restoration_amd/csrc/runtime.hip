@@ -186,14 +186,17 @@ PackedW pack_upload_1x1(WeightPool& pool, const float* w, const float* bias, int
   out.M = M; out.K = K; out.Cin = K;
   return out;
 }
-PackedW pack_upload_3x3(WeightPool& pool, const float* w, const float* bias, int M, int Cin) {
+PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, int M, int Cin, int ks) {
   std::vector<float> packed;
   PackedW out;
-  pack_wt_3x3(w, M, Cin, packed, &out.Mpad);
+  pack_wt_conv(w, M, Cin, ks, packed, &out.Mpad);
   out.wt = pool.upload(packed);
   out.bias = bias ? pool.upload(bias, M) : nullptr;
-  out.M = M; out.K = 9 * Cin; out.Cin = Cin;
+  out.M = M; out.K = ks * ks * Cin; out.Cin = Cin;
   return out;
+}
+PackedW pack_upload_3x3(WeightPool& pool, const float* w, const float* bias, int M, int Cin) {
+  return pack_upload_conv(pool, w, bias, M, Cin, 3);
 }
 
 // ---- kernel clock -----------------------------------------------------------------------------

@@ -170,3 +170,56 @@ def make_astv2_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0) 
         conv("skip_conv", 2 * dim, dim, 1, bias)
     conv("output", cout, 2 * dim, 3, bias)
     return g.sd
+
+
+def make_ast_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """AST state dict (ast_arch.py:95-117,219-273,453-474,561-596,600-674,940-1198 constructors),
+    token_mlp="frfn".  Includes the int32 `relative_position_index` buffers like a saved checkpoint."""
+    from .ast_oracle import block_window, default_config, layer_plan, relative_position_index
+    cfg = cfg or default_config()
+    g = _Gen(seed, gain)
+    E = cfg["embed_dim"]
+    ratio = cfg.get("mlp_ratio", 4.0)
+    qkv_bias = cfg.get("qkv_bias", True)
+
+    def linear(key, co, ci, bias=True):
+        g.kernel(key + ".weight", (co, ci))
+        if bias:
+            g.vec(key + ".bias", co, 0.0, 0.05)
+
+    g.kernel("input_proj.proj.0.weight", (E, cfg.get("dd_in", 3), 3, 3))
+    g.vec("input_proj.proj.0.bias", E, 0.0, 0.05)
+    g.kernel("output_proj.proj.0.weight", (cfg.get("in_chans", 3), 2 * E, 3, 3))
+    g.vec("output_proj.proj.0.bias", cfg.get("in_chans", 3), 0.0, 0.05)
+    for name, mult, div, depth, heads, att in layer_plan(cfg):
+        c = E * mult
+        h = int(c * ratio)
+        for i in range(depth):
+            pre = f"{name}.blocks.{i}"
+            if att:
+                win, _ = block_window(cfg, div, i)
+                g.vec(pre + ".norm1.weight", c, 1.0, 0.1)
+                g.vec(pre + ".norm1.bias", c, 0.0, 0.1)
+                a = pre + ".attn"
+                g.sd[a + ".relative_position_bias_table"] = (
+                    g.rng.standard_normal(((2 * win - 1) ** 2, heads)) * 0.2).astype(np.float32)
+                g.sd[a + ".relative_position_index"] = relative_position_index(win).numpy().astype(np.int32)
+                linear(a + ".qkv.to_q", c, c, qkv_bias)
+                linear(a + ".qkv.to_kv", 2 * c, c, qkv_bias)
+                linear(a + ".proj", c, c)
+                g.sd[a + ".w"] = g.rng.uniform(-1.0, 1.0, 2).astype(np.float32)
+            g.vec(pre + ".norm2.weight", c, 1.0, 0.1)
+            g.vec(pre + ".norm2.bias", c, 0.0, 0.1)
+            m = pre + ".mlp"
+            linear(m + ".linear1.0", 2 * h, c)
+            g.kernel(m + ".dwconv.0.weight", (h, 1, 3, 3))
+            g.vec(m + ".dwconv.0.bias", h, 0.0, 0.05)
+            linear(m + ".linear2.0", c, h)
+            g.kernel(m + ".partial_conv3.weight", (c // 4, c // 4, 3, 3))
+    for i, (ci, co) in enumerate(((E, 2 * E), (2 * E, 4 * E), (4 * E, 8 * E), (8 * E, 16 * E))):
+        g.kernel(f"dowsample_{i}.conv.0.weight", (co, ci, 4, 4))
+        g.vec(f"dowsample_{i}.conv.0.bias", co, 0.0, 0.05)
+    for i, (ci, co) in enumerate(((16 * E, 8 * E), (16 * E, 4 * E), (8 * E, 2 * E), (4 * E, E))):
+        g.kernel(f"upsample_{i}.deconv.0.weight", (ci, co, 2, 2), fan_in=ci)
+        g.vec(f"upsample_{i}.deconv.0.bias", co, 0.0, 0.05)
+    return g.sd
