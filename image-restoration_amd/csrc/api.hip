@@ -350,9 +350,12 @@ int jirf_op_hint_attention_core(const float* qkv, const float* params_host, cons
     p += 4;
     for (int g = 0; g < 4; ++g) {
       const int c = sh.gsz[g];
-      w.cw_w[g] = pool.upload(p, (size_t)2 * c * c); p += (size_t)2 * c * c;
+      std::vector<float> packed;
+      pack_hint_modulator(p, 2 * c, c, packed);
+      w.cw_wt[g] = pool.upload(packed); p += (size_t)2 * c * c;
       w.cw_b[g] = pool.upload(p, (size_t)2 * c); p += 2 * c;
-      w.gc_w[g] = pool.upload(p, (size_t)c * c); p += (size_t)c * c;
+      pack_hint_modulator(p, c, c, packed);
+      w.gc_wt[g] = pool.upload(packed); p += (size_t)c * c;
       w.gc_b[g] = pool.upload(p, (size_t)c); p += c;
     }
     HintAttnScratch sc;

@@ -130,13 +130,15 @@ struct HintAttnShape {
 };
 HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode);
 
-struct HintAttnWeights {   // device pointers, reference layouts
+struct HintAttnWeights {   // device pointers
   const float* temperature;             // [4]
-  const float* cw_w[4];                 // conv_width.weight [2c][c]
+  const float* cw_wt[4];                // conv_width.weight packed K-major by pack_hint_modulator: [c][2c -> x32]
   const float* cw_b[4];                 // [2c]
-  const float* gc_w[4];                 // gating_conv.weight [c][c]
+  const float* gc_wt[4];                // gating_conv.weight packed K-major: [c][c -> x32]
   const float* gc_b[4];                 // [c]
 };
+// w [M][K] (a Conv1d(k=1) kernel) -> [K][M rounded up to 32], zero padded
+void pack_hint_modulator(const float* w, int M, int K, std::vector<float>& out);
 
 struct HintAttnScratch {   // device scratch, carved by hint_attn_scratch_carve
   double* gram_part;   // [G][splits][C][C]
@@ -152,6 +154,7 @@ struct HintAttnScratch {   // device scratch, carved by hint_attn_scratch_carve
   float* att_t;        // [B][Kpad][Mpad] block-diagonal attention, transposed (GEMM weight layout)
   float* att_nat;      // [B][C][C] block-diagonal attention, natural orientation
   float* pooled;       // [G][C][C] carried cache pooled to this block's C
+  float* pooled_g;     // [G][sum c_g^2] the same pooled once more to every group's c x c
 };
 // Lays the scratch out from `base` (may be null to size it) and returns the bytes needed.
 size_t hint_attn_scratch_carve(const HintAttnShape& sh, void* base, HintAttnScratch* out);

@@ -53,12 +53,17 @@ struct StatsArgs {
   float* k2_part;    // [nb][splits][C]
 };
 
-template <bool DO_QK, bool DO_GRAM>
+// Tiles staged per 32-pixel chunk (64 channel rows each, row stride 33 floats):
+//   A  rows of the i tile of q (of the gram source when only the gram is computed)
+//   B  rows of the j tile of k                       (DO_QK)
+//   Cg rows of the j tile of the gram source         (DO_GRAM; aliases A on diagonal tile pairs)
+// The next chunk is fetched into registers while the current one is multiplied (LDS double
+// buffer, one barrier per chunk).
+template <bool DO_QK, bool DO_GRAM, bool VEC>
 __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
-  __shared__ float Qi[ST_T * ST_LD];
-  __shared__ float Kj[DO_QK ? ST_T * ST_LD : 1];
-  __shared__ float Gi[DO_GRAM ? ST_T * ST_LD : 1];
-  __shared__ float Gj[DO_GRAM ? ST_T * ST_LD : 1];
+  __shared__ float TA[2][ST_T * ST_LD];
+  __shared__ float TB[DO_QK ? 2 : 1][DO_QK ? ST_T * ST_LD : 1];
+  __shared__ float TC[DO_GRAM ? 2 : 1][DO_GRAM ? ST_T * ST_LD : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
@@ -75,10 +80,12 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
   }
   const int c_begin = sp * a.chunks_per_split;
   const int c_end = min(c_begin + a.chunks_per_split, (P + ST_CH - 1) / ST_CH);
+  // an empty split (c_begin >= c_end) still writes its all-zero slab: the reduction reads every slab
 
-  const float* __restrict__ qb = a.q + (long)b * a.q_bs;
-  const float* __restrict__ kb = a.k + (long)b * a.k_bs;
-  const float* __restrict__ gb = a.qg + (long)b * a.qg_bs;
+  const float* __restrict__ src_a = (DO_QK ? a.q + (long)b * a.q_bs : a.qg + (long)b * a.qg_bs);
+  const float* __restrict__ src_b = a.k + (long)b * a.k_bs;
+  const float* __restrict__ src_c = a.qg + (long)b * a.qg_bs;
+  const bool c_is_a = DO_GRAM && ti == tj && src_c == src_a;
 
   f32x16 s_acc;
   f64x4 g_acc[2][2];
@@ -90,43 +97,70 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) g_acc[t][u][r] = 0.0;
-  double row_sum = 0.0;  // threads 0..63: sum of gram-source row i0+tid
-  float row_sq = 0.f;    // threads 0..63: sum q^2 of row i0+tid ; threads 64..127: sum k^2 of row j0+tid-64
+  double row_sum = 0.0;  // threads 128..191: sum of the gram-source row i0 + tid - 128
+  float row_sq = 0.f;    // threads 0..63: sum q^2 of row i0 + tid; threads 64..127: sum k^2 of row j0 + tid - 64
 
-  // staging: 64 rows x 32 px = 512 float4 slots, two per thread
-  auto stage = [&](float* dst, const float* __restrict__ src, int r0, int px0) {
+  // 64 rows x 32 px = 512 float4 slots per tile, two per thread
+  auto fetch = [&](const float* __restrict__ src, int r0, int px0, float4* out) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int s = tid + it * 256;
-      const int r = s >> 3, c4 = (s & 7) * 4;
-      const int row = r0 + r, px = px0 + c4;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      const int row = r0 + (s >> 3), px = px0 + (s & 7) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < C) {
         const float* __restrict__ ptr = src + (long)row * P + px;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (px + e < P) v[e] = ptr[e];
+        if constexpr (VEC) {
+          if (px < P) v = *reinterpret_cast<const float4*>(ptr);
+        } else {
+          if (px < P) v.x = ptr[0];
+          if (px + 1 < P) v.y = ptr[1];
+          if (px + 2 < P) v.z = ptr[2];
+          if (px + 3 < P) v.w = ptr[3];
+        }
       }
+      out[it] = v;
+    }
+  };
+  auto put = [&](float* dst, const float4* in) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dst[r * ST_LD + c4 + e] = v[e];
+    for (int it = 0; it < 2; ++it) {
+      const int s = tid + it * 256;
+      float* __restrict__ d = dst + (s >> 3) * ST_LD + (s & 7) * 4;
+      d[0] = in[it].x; d[1] = in[it].y; d[2] = in[it].z; d[3] = in[it].w;
+    }
+  };
+  float4 ra[2], rb[2], rc[2];
+  auto fetch_all = [&](int ch) {
+    const int px0 = ch * ST_CH;
+    fetch(src_a, i0, px0, ra);
+    if constexpr (DO_QK) fetch(src_b, j0, px0, rb);
+    if constexpr (DO_GRAM) {
+      if (!c_is_a) fetch(src_c, j0, px0, rc);
+    }
+  };
+  auto put_all = [&](int buf) {
+    put(TA[buf], ra);
+    if constexpr (DO_QK) put(TB[buf], rb);
+    if constexpr (DO_GRAM) {
+      if (!c_is_a) put(TC[buf], rc);
     }
   };
 
+  if (c_begin < c_end) {
+    fetch_all(c_begin);
+    put_all(0);
+  }
+  __syncthreads();
+  const bool quad_on = i0 + wi * 32 < C && j0 + wj * 32 < C;
   for (int ch = c_begin; ch < c_end; ++ch) {
-    const int px0 = ch * ST_CH;
+    const int buf = (ch - c_begin) & 1;
+    if (ch + 1 < c_end) fetch_all(ch + 1);
+    const float* __restrict__ A = TA[buf];
     if constexpr (DO_QK) {
-      stage(Qi, qb, i0, px0);
-      stage(Kj, kb, j0, px0);
-    }
-    if constexpr (DO_GRAM) {
-      stage(Gi, gb, i0, px0);
-      stage(Gj, gb, j0, px0);
-    }
-    __syncthreads();
-    if constexpr (DO_QK) {
-      if (i0 + wi * 32 < C && j0 + wj * 32 < C) {
-        const float* __restrict__ ap = &Qi[(wi * 32 + l31) * ST_LD + half];
-        const float* __restrict__ bp = &Kj[(wj * 32 + l31) * ST_LD + half];
+      const float* __restrict__ Bt = TB[buf];
+      if (quad_on) {
+        const float* __restrict__ ap = &A[(wi * 32 + l31) * ST_LD + half];
+        const float* __restrict__ bp = &Bt[(wj * 32 + l31) * ST_LD + half];
 #pragma unroll
         for (int s = 0; s < ST_CH / 2; ++s)
           s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], s_acc, 0, 0, 0);
@@ -134,26 +168,27 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
       if (tj == ti && tid < 64) {
         float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < ST_CH; ++e) t = fmaf(Qi[tid * ST_LD + e], Qi[tid * ST_LD + e], t);
+        for (int e = 0; e < ST_CH; ++e) t = fmaf(A[tid * ST_LD + e], A[tid * ST_LD + e], t);
         row_sq += t;
       }
       if (ti == tj && tid >= 64 && tid < 128) {
         const int r = tid - 64;
         float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < ST_CH; ++e) t = fmaf(Kj[r * ST_LD + e], Kj[r * ST_LD + e], t);
+        for (int e = 0; e < ST_CH; ++e) t = fmaf(Bt[r * ST_LD + e], Bt[r * ST_LD + e], t);
         row_sq += t;
       }
     }
     if constexpr (DO_GRAM) {
-      if (i0 + wi * 32 < C && j0 + wj * 32 < C) {
+      const float* __restrict__ Ct = c_is_a ? A : TC[buf];
+      if (quad_on) {
 #pragma unroll
         for (int s = 0; s < ST_CH / 4; ++s) {
           double av[2], bv[2];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            av[t] = (double)Gi[(wi * 32 + t * 16 + l15) * ST_LD + 4 * s + quad];
-            bv[t] = (double)Gj[(wj * 32 + t * 16 + l15) * ST_LD + 4 * s + quad];
+            av[t] = (double)A[(wi * 32 + t * 16 + l15) * ST_LD + 4 * s + quad];
+            bv[t] = (double)Ct[(wj * 32 + t * 16 + l15) * ST_LD + 4 * s + quad];
           }
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -166,10 +201,11 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
         const int r = tid - 128;
         double t = 0.0;
 #pragma unroll
-        for (int e = 0; e < ST_CH; ++e) t += (double)Gi[r * ST_LD + e];
+        for (int e = 0; e < ST_CH; ++e) t += (double)A[r * ST_LD + e];
         row_sum += t;
       }
     }
+    if (ch + 1 < c_end) put_all(buf ^ 1);
     __syncthreads();
   }
 
@@ -200,6 +236,20 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatsArgs a) {
     if (tj == ti && tid >= 128 && tid < 192 && i0 + tid - 128 < C)
       a.qsum_part[slab + i0 + tid - 128] = row_sum;
   }
+}
+
+template <bool DO_QK, bool DO_GRAM>
+static void launch_chan_stats(const StatsArgs& st, int nb, hipStream_t s) {
+  auto ok = [&](const float* p, long bs) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && bs % 4 == 0; };
+  bool vec = st.P % 4 == 0;
+  if (DO_QK) vec = vec && ok(st.q, st.q_bs) && ok(st.k, st.k_bs);
+  if (DO_GRAM) vec = vec && ok(st.qg, st.qg_bs);
+  const dim3 grid(st.tiles * st.tiles, st.splits, nb), block(256);
+  if (vec)
+    hipLaunchKernelGGL((chan_stats_kernel<DO_QK, DO_GRAM, true>), grid, block, 0, s, st);
+  else
+    hipLaunchKernelGGL((chan_stats_kernel<DO_QK, DO_GRAM, false>), grid, block, 0, s, st);
+  JIRF_HIP_CHECK(hipGetLastError());
 }
 
 // batch mean of q for the coupled mode: qmean[c][p] = mean_b q[b][c][p]
@@ -311,6 +361,8 @@ __global__ __launch_bounds__(256) void cache_pool_kernel(const float* __restrict
 struct GroupAttnArgs {
   int C, G, ipg, Mpad;
   int gsz[4], goff[4];
+  int poff[4];              // offset of group g inside a pooled_g / compact row (sum of c^2 before it)
+  int psum;                 // sum of c_g^2
   const double* sim;        // [G][C]
   const int* forced_perm;   // [G][C] or null
   int* perm_out;            // [G][C]
@@ -319,19 +371,27 @@ struct GroupAttnArgs {
   const float* rk;          // [B][C]
   const float* temperature; // [4]
   const float* pooled;      // [G][C][C] or null (no cache)
-  const float* cw_w[4];
+  const float* pooled_g;    // [G][psum]: the cache pooled to every group's c x c
+  const float* cw_wt[4];    // conv_width.weight, K-major [c][mp2] (mp2 = 2c rounded up to 32)
   const float* cw_b[4];
-  const float* gc_w[4];
+  const float* gc_wt[4];    // gating_conv.weight, K-major [c][mp1]
   const float* gc_b[4];
+  int n_chunks;             // column chunks of the modulation kernel
+  int chunk_g[32], chunk_j0[32];
   float* att_t;             // [B][Kpad][Mpad]
   float* att_nat;           // [B][C][C]
 };
 
-constexpr int GA_JC = 32;  // columns modulated per pass
+constexpr int GA_JC = 32;   // columns modulated per workgroup
+constexpr int GA_LD = 33;   // LDS row stride of the 32-column chunk images
 
 __device__ __forceinline__ double sort_key(double v) { return v != v ? -INFINITY : v; }
 
-__global__ __launch_bounds__(256) void group_attn_kernel(const GroupAttnArgs a) {
+// ---- 3a. permutation, gather, scale, row softmax ---------------------------------------------------
+// One workgroup per (group, image).  Writes the softmax block in natural orientation; without a
+// cache that is already the final attention, so the transposed (GEMM weight) image is written too.
+// Either way the off-diagonal part of the rows this group owns in the transposed image is zeroed.
+__global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ga_smem[];
   const int gi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, c = a.gsz[gi], off = a.goff[gi];
@@ -340,8 +400,6 @@ __global__ __launch_bounds__(256) void group_attn_kernel(const GroupAttnArgs a) 
   double* key = reinterpret_cast<double*>(ga_smem);            // [C]
   int* perm = reinterpret_cast<int*>(key + C);                 // [C]
   float* X = reinterpret_cast<float*>(perm + C + (C & 1));     // [c][ld]
-  float* XP = X + c * ld;                                      // [c][JC]
-  float* Y = XP + c * GA_JC;                                   // [c][JC]
 
   // ---- channel permutation: descending similarity, ties by ascending channel ----
   if (a.forced_perm) {
@@ -372,7 +430,6 @@ __global__ __launch_bounds__(256) void group_attn_kernel(const GroupAttnArgs a) 
     X[r * ld + s] = S[(long)ci * C + cj] * a.rq[(long)b * C + ci] * a.rk[(long)b * C + cj] * temp;
   }
   __syncthreads();
-  // ---- row softmax (one wave per row) ----
   {
     const int lane = tid & 63, wave = tid >> 6;
     for (int r = wave; r < c; r += 4) {
@@ -392,84 +449,134 @@ __global__ __launch_bounds__(256) void group_attn_kernel(const GroupAttnArgs a) 
   }
   __syncthreads();
 
-  float* __restrict__ att_t = a.att_t + (long)b * (((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD) * a.Mpad;
+  const int kpad = ((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD;
+  float* __restrict__ att_t = a.att_t + (long)b * kpad * a.Mpad;
   float* __restrict__ att_nat = a.att_nat + (long)b * C * C;
+  for (int e = tid; e < c * c; e += 256) {
+    const int r = e / c, s = e - r * c;
+    att_nat[(long)(off + r) * C + off + s] = X[r * ld + s];
+  }
+  // rows [off, off + c) of the transposed image belong to this group (the last group also owns
+  // the padding rows)
+  const int row_end = gi == 3 ? kpad : off + c;
+  const bool final_here = a.pooled == nullptr;
+  for (int e = tid; e < (row_end - off) * a.Mpad; e += 256) {
+    const int kr = off + e / a.Mpad, m = e % a.Mpad;
+    const bool inside = kr < off + c && m >= off && m < off + c;
+    if (!inside)
+      att_t[(long)kr * a.Mpad + m] = 0.f;
+    else if (final_here)
+      att_t[(long)kr * a.Mpad + m] = X[(m - off) * ld + (kr - off)];
+  }
+}
 
-  // Rows [off, off + c) of the transposed image belong to this group (the last group also owns
-  // the padding rows); everything outside the diagonal block must read as zero in the GEMM.
+// ---- 3b. the cache pooled to every group's c x c (Inter_CacheModulation.align) ---------------------
+__global__ __launch_bounds__(256) void cache_pool_groups_kernel(const GroupAttnArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (idx >= a.psum) return;
+  int gi = 3;
+  while (gi > 0 && idx < a.poff[gi]) --gi;
+  const int c = a.gsz[gi], C = a.C;
+  const int e = idx - a.poff[gi];
+  const int r = e / c, s = e - r * c;
+  const float* __restrict__ src = a.pooled + (long)g * C * C;
+  const int ys = pool_start(r, C, c), ye = pool_end(r, C, c);
+  const int xs = pool_start(s, C, c), xe = pool_end(s, C, c);
+  double acc = 0.0;
+  for (int y = ys; y < ye; ++y)
+    for (int x = xs; x < xe; ++x) acc += (double)src[(long)y * C + x];
+  const_cast<float*>(a.pooled_g)[(long)g * a.psum + idx] = (float)(acc / (double)((ye - ys) * (xe - xs)));
+}
+
+// ---- 3c. inter-cache modulation -----------------------------------------------------------------------
+// Conv1d(k=1) mixes ROWS of the c x c attention block, so columns are independent: one workgroup
+// per (group, 32-column chunk, image).  With X the softmax block and Pg the pooled cache:
+//   Z = Ww (Pg + X) + bw ;  Y = X * Z[:c] + Z[c:] ;  att = Y * gelu(Wg Y + bg) + X
+// Both products run on fp32 MFMA (32x32x2): A = K-major packed weights straight from global
+// (128-byte rows), B = the chunk image in LDS.
+__global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+  const int gi = a.chunk_g[blockIdx.x], j0 = a.chunk_j0[blockIdx.x];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int C = a.C, c = a.gsz[gi], off = a.goff[gi];
+  const int g = b / a.ipg;
+  const int nj = min(GA_JC, c - j0);
+  const int mp2 = (2 * c + 31) / 32 * 32, mp1 = (c + 31) / 32 * 32;
+  float* Xs = reinterpret_cast<float*>(gm_smem);   // [c][GA_LD]  softmax chunk
+  float* XP = Xs + c * GA_LD;                      // [c][GA_LD]  X + pooled cache
+  float* Ys = XP + c * GA_LD;                      // [c][GA_LD]
+  float* Zs = Ys + c * GA_LD;                      // [mp2][GA_LD]
+  float* __restrict__ att_nat = a.att_nat + (long)b * C * C;
+  const float* __restrict__ pg = a.pooled_g + (long)g * a.psum + a.poff[gi];
+
+  for (int e = tid; e < c * GA_JC; e += 256) {
+    const int r = e >> 5, jj = e & 31;
+    float x = 0.f, xp = 0.f;
+    if (jj < nj) {
+      x = att_nat[(long)(off + r) * C + off + j0 + jj];
+      xp = x + pg[r * c + j0 + jj];
+    }
+    Xs[r * GA_LD + jj] = x;
+    XP[r * GA_LD + jj] = xp;
+  }
+  __syncthreads();
+
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  // Z = Ww XP + bw
   {
+    const float* __restrict__ Wt = a.cw_wt[gi];
+    const float* __restrict__ bw = a.cw_b[gi];
+    for (int mt = wave; mt < mp2 / 32; mt += 4) {
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* __restrict__ ap = Wt + (long)half * mp2 + mt * 32 + l31;
+      const float* __restrict__ bp = XP + half * GA_LD + l31;
+#pragma unroll 4
+      for (int k0 = 0; k0 < c; k0 += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(long)k0 * mp2], bp[k0 * GA_LD], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        Zs[row * GA_LD + l31] = acc[r] + (row < 2 * c ? bw[row] : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < c * GA_JC; e += 256) {
+    const int o = e >> 5, jj = e & 31;
+    Ys[o * GA_LD + jj] = jj < nj ? Xs[o * GA_LD + jj] * Zs[o * GA_LD + jj] + Zs[(c + o) * GA_LD + jj] : 0.f;
+  }
+  __syncthreads();
+  // att = Y * gelu(Wg Y + bg) + X
+  {
+    const float* __restrict__ Wt = a.gc_wt[gi];
+    const float* __restrict__ bg = a.gc_b[gi];
     const int kpad = ((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD;
-    const int row_end = gi == 3 ? kpad : off + c;
-    for (int e = tid; e < (row_end - off) * a.Mpad; e += 256) {
-      const int kr = off + e / a.Mpad, m = e % a.Mpad;
-      if (kr >= off + c || m < off || m >= off + c) att_t[(long)kr * a.Mpad + m] = 0.f;
-    }
-  }
-
-  if (!a.pooled) {
-    for (int e = tid; e < c * c; e += 256) {
-      const int r = e / c, s = e - r * c;
-      const float v = X[r * ld + s];
-      att_nat[(long)(off + r) * C + off + s] = v;
-    }
-    for (int e = tid; e < c * c; e += 256) {  // transposed store, m (row) fastest
-      const int s = e / c, r = e - s * c;
-      att_t[(long)(off + s) * a.Mpad + off + r] = X[r * ld + s];
-    }
-    return;
-  }
-
-  // ---- inter-cache modulation, JC columns at a time (Conv1d(k=1) mixes rows, so columns are
-  //      independent):  Z = Ww (pool(cache) + X) + bw ; Y = X * Z[:c] + Z[c:] ;
-  //      att = Y * gelu(Wg Y + bg) + X ----
-  const float* __restrict__ pooled = a.pooled + (long)g * C * C;
-  const float* __restrict__ Ww = a.cw_w[gi];
-  const float* __restrict__ bw = a.cw_b[gi];
-  const float* __restrict__ Wg = a.gc_w[gi];
-  const float* __restrict__ bg = a.gc_b[gi];
-  for (int jc = 0; jc < c; jc += GA_JC) {
-    const int nj = min(GA_JC, c - jc);
-    // pooled cache (C x C -> c x c) + X
-    for (int e = tid; e < c * GA_JC; e += 256) {
-      const int r = e / GA_JC, jj = e - r * GA_JC;
-      float v = 0.f;
-      if (jj < nj) {
-        const int s = jc + jj;
-        const int ys = pool_start(r, C, c), ye = pool_end(r, C, c);
-        const int xs = pool_start(s, C, c), xe = pool_end(s, C, c);
-        double acc = 0.0;
-        for (int y = ys; y < ye; ++y)
-          for (int x = xs; x < xe; ++x) acc += (double)pooled[(long)y * C + x];
-        v = (float)(acc / (double)((ye - ys) * (xe - xs))) + X[r * ld + s];
+    float* __restrict__ att_t = a.att_t + (long)b * kpad * a.Mpad;
+    for (int mt = wave; mt < mp1 / 32; mt += 4) {
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* __restrict__ ap = Wt + (long)half * mp1 + mt * 32 + l31;
+      const float* __restrict__ bp = Ys + half * GA_LD + l31;
+#pragma unroll 4
+      for (int k0 = 0; k0 < c; k0 += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(long)k0 * mp1], bp[k0 * GA_LD], acc, 0, 0, 0);
+      if (l31 < nj) {
+        const int s = j0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (o >= c) continue;
+          const float v = Ys[o * GA_LD + l31] * gelu_erf_a(acc[r] + bg[o]) + Xs[o * GA_LD + l31];
+          att_nat[(long)(off + o) * C + off + s] = v;
+          att_t[(long)(off + s) * a.Mpad + off + o] = v;
+        }
       }
-      XP[r * GA_JC + jj] = v;
     }
-    __syncthreads();
-    for (int e = tid; e < c * GA_JC; e += 256) {
-      const int o = e / GA_JC, jj = e - o * GA_JC;
-      float sc = bw[o], sh = bw[c + o];
-      const float* __restrict__ w0 = Ww + (long)o * c;
-      const float* __restrict__ w1 = Ww + (long)(c + o) * c;
-      for (int i = 0; i < c; ++i) {
-        const float xv = XP[i * GA_JC + jj];
-        sc = fmaf(w0[i], xv, sc);
-        sh = fmaf(w1[i], xv, sh);
-      }
-      Y[o * GA_JC + jj] = jj < nj ? X[o * ld + jc + jj] * sc + sh : 0.f;
-    }
-    __syncthreads();
-    for (int e = tid; e < c * GA_JC; e += 256) {
-      const int o = e / GA_JC, jj = e - o * GA_JC;
-      if (jj >= nj) continue;
-      float gt = bg[o];
-      const float* __restrict__ w0 = Wg + (long)o * c;
-      for (int i = 0; i < c; ++i) gt = fmaf(w0[i], Y[i * GA_JC + jj], gt);
-      const int s = jc + jj;
-      const float v = Y[o * GA_JC + jj] * gelu_erf_a(gt) + X[o * ld + s];
-      att_nat[(long)(off + o) * C + off + s] = v;
-      att_t[(long)(off + s) * a.Mpad + off + o] = v;
-    }
-    __syncthreads();
   }
 }
 
@@ -556,6 +663,13 @@ HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode) {
 
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+void pack_hint_modulator(const float* w, int M, int K, std::vector<float>& out) {
+  const int mp = (M + 31) / 32 * 32;
+  out.assign((size_t)K * mp, 0.f);
+  for (int o = 0; o < M; ++o)
+    for (int k = 0; k < K; ++k) out[(size_t)k * mp + o] = w[(size_t)o * K + k];
+}
+
 size_t hint_attn_scratch_carve(const HintAttnShape& sh, void* base, HintAttnScratch* o) {
   size_t off = 0;
   const size_t C = sh.C, B = sh.B, G = sh.G, S = sh.splits;
@@ -579,6 +693,7 @@ size_t hint_attn_scratch_carve(const HintAttnShape& sh, void* base, HintAttnScra
   o->att_t = static_cast<float*>(take(B * kpad * mpad * 4));
   o->att_nat = static_cast<float*>(take(B * C * C * 4));
   o->pooled = static_cast<float*>(take(G * C * C * 4));
+  o->pooled_g = static_cast<float*>(take(G * C * C * 4));  // sum of c_g^2 <= C^2
   return off;
 }
 
@@ -606,8 +721,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
   if (ipg == 1) {
     st.qg = q.p; st.qg_bs = q.bs;
     Scope scope(intern_label("hint_chan_stats C%d P%d S%d", C, P, sh.splits), 4.0 * tile_px * B, 8.0 * B * (double)C * P, s);
-    hipLaunchKernelGGL((chan_stats_kernel<true, true>), dim3(tiles * tiles, sh.splits, B), dim3(256),
-                       0, s, st);
+    launch_chan_stats<true, true>(st, B, s);
   } else {
     {
       Scope scope("hint_batch_mean", (double)B * C * P, 4.0 * (B + 1) * (double)C * P, s);
@@ -617,13 +731,11 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     }
     {
       Scope scope("hint_chan_stats", 2.0 * tile_px * B, 8.0 * B * (double)C * P, s);
-      hipLaunchKernelGGL((chan_stats_kernel<true, false>), dim3(tiles * tiles, sh.splits, B),
-                         dim3(256), 0, s, st);
+      launch_chan_stats<true, false>(st, B, s);
     }
     st.qg = sc.qmean; st.qg_bs = 0;
     Scope scope("hint_chan_stats", 2.0 * tile_px, 4.0 * (double)C * P, s);
-    hipLaunchKernelGGL((chan_stats_kernel<false, true>), dim3(tiles * tiles, sh.splits, 1), dim3(256),
-                       0, s, st);
+    launch_chan_stats<false, true>(st, 1, s);
   }
   JIRF_HIP_CHECK(hipGetLastError());
   {
@@ -647,30 +759,53 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     GroupAttnArgs ga{};
     ga.C = C; ga.G = G; ga.ipg = ipg;
     ga.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
-    int cmax = 0;
+    int cmax = 0, psum = 0, nch = 0;
     for (int i = 0; i < 4; ++i) {
       ga.gsz[i] = sh.gsz[i]; ga.goff[i] = sh.goff[i];
-      ga.cw_w[i] = w.cw_w[i]; ga.cw_b[i] = w.cw_b[i]; ga.gc_w[i] = w.gc_w[i]; ga.gc_b[i] = w.gc_b[i];
+      ga.cw_wt[i] = w.cw_wt[i]; ga.cw_b[i] = w.cw_b[i]; ga.gc_wt[i] = w.gc_wt[i]; ga.gc_b[i] = w.gc_b[i];
       cmax = std::max(cmax, sh.gsz[i]);
+      ga.poff[i] = psum;
+      psum += sh.gsz[i] * sh.gsz[i];
+      for (int j0 = 0; j0 < sh.gsz[i]; j0 += GA_JC) {
+        JIRF_REQUIRE(nch < 32, JIRF_EINVAL, "hint attention: C=%d needs more than 32 column chunks", C);
+        ga.chunk_g[nch] = i;
+        ga.chunk_j0[nch] = j0;
+        ++nch;
+      }
     }
+    ga.psum = psum; ga.n_chunks = nch;
     ga.sim = sim; ga.forced_perm = forced_perm; ga.perm_out = perm_out;
     ga.s_qk = sc.s_qk; ga.rq = sc.rq; ga.rk = sc.rk; ga.temperature = w.temperature;
-    ga.pooled = pooled; ga.att_t = sc.att_t; ga.att_nat = sc.att_nat;
-    const size_t smem = (size_t)C * 8 + ((size_t)C + (C & 1)) * 4 +
-                        ((size_t)cmax * (cmax + 1) + 2 * (size_t)cmax * GA_JC) * 4;
-    JIRF_REQUIRE(smem <= 160 * 1024, JIRF_EINVAL,
-                 "hint attention: channel group of %d does not fit LDS (%zu bytes)", cmax, smem);
+    ga.pooled = pooled; ga.pooled_g = sc.pooled_g; ga.att_t = sc.att_t; ga.att_nat = sc.att_nat;
+    const size_t smem_a = (size_t)C * 8 + ((size_t)C + (C & 1)) * 4 + (size_t)cmax * (cmax + 1) * 4;
+    const size_t smem_c = ((size_t)3 * cmax + (2 * cmax + 31) / 32 * 32) * GA_LD * 4;
+    JIRF_REQUIRE(smem_a <= 160 * 1024 && smem_c <= 160 * 1024, JIRF_EINVAL,
+                 "hint attention: channel group of %d does not fit LDS (%zu / %zu bytes)", cmax, smem_a, smem_c);
     static bool attr_set = false;
     if (!attr_set) {
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_attn_kernel),
+      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_softmax_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_modulate_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    double fl = 0.0;
-    for (int i = 0; i < 4; ++i) fl += (pooled ? 6.0 : 0.0) * sh.gsz[i] * (double)sh.gsz[i] * sh.gsz[i];
-    Scope scope(intern_label("hint_group_attn C%d", C), fl * B, 12.0 * B * (double)C * C, s);
-    hipLaunchKernelGGL(group_attn_kernel, dim3(4, B), dim3(256), smem, s, ga);
-    JIRF_HIP_CHECK(hipGetLastError());
+    {
+      Scope scope(intern_label("hint_group_softmax C%d", C), 0.0, 12.0 * B * (double)C * C, s);
+      hipLaunchKernelGGL(group_softmax_kernel, dim3(4, B), dim3(256), smem_a, s, ga);
+      JIRF_HIP_CHECK(hipGetLastError());
+    }
+    if (pooled) {
+      {
+        Scope scope("hint_cache_pool_groups", 0.0, 4.0 * G * ((double)C * C + psum), s);
+        hipLaunchKernelGGL(cache_pool_groups_kernel, dim3((psum + 255) / 256, G), dim3(256), 0, s, ga);
+        JIRF_HIP_CHECK(hipGetLastError());
+      }
+      double fl = 0.0;
+      for (int i = 0; i < 4; ++i) fl += 6.0 * sh.gsz[i] * (double)sh.gsz[i] * sh.gsz[i];
+      Scope scope(intern_label("hint_group_modulate C%d", C), fl * B, 16.0 * B * (double)psum, s);
+      hipLaunchKernelGGL(group_modulate_kernel, dim3(nch, B), dim3(256), smem_c, s, ga);
+      JIRF_HIP_CHECK(hipGetLastError());
+    }
   }
   {
     CacheUpdArgs cu{};
@@ -802,8 +937,7 @@ void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const flo
   {
     Scope scope(intern_label("head_chan_stats C%d P%d S%d", C, P, splits), 2.0 * C * (double)ch * P * B,
                 8.0 * B * (double)C * P, s);
-    hipLaunchKernelGGL((chan_stats_kernel<true, false>), dim3(tiles * tiles, splits, B), dim3(256), 0, s, st);
-    JIRF_HIP_CHECK(hipGetLastError());
+    launch_chan_stats<true, false>(st, B, s);
   }
   {
     Scope scope("head_reduce_rows", 1.0 * C * (double)C * splits * B, 4.0 * C * (double)C * splits * B, s);

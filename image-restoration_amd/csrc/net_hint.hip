@@ -121,9 +121,13 @@ class HintNet final : public Net {
           bl.aw.temperature = vec(a + ".temperature");
           for (int g = 0; g < 4; ++g) {
             const std::string m = a + ".inter_modulator" + std::to_string(g + 1);
-            bl.aw.cw_w[g] = vec(m + ".conv_width.weight");
+            const int cg = (int)host(m + ".gating_conv.bias").size();
+            std::vector<float> packed;
+            pack_hint_modulator(host(m + ".conv_width.weight").data(), 2 * cg, cg, packed);
+            bl.aw.cw_wt[g] = pool_.upload(packed);
             bl.aw.cw_b[g] = vec(m + ".conv_width.bias");
-            bl.aw.gc_w[g] = vec(m + ".gating_conv.weight");
+            pack_hint_modulator(host(m + ".gating_conv.weight").data(), cg, cg, packed);
+            bl.aw.gc_wt[g] = pool_.upload(packed);
             bl.aw.gc_b[g] = vec(m + ".gating_conv.bias");
           }
         }

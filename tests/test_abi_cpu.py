@@ -122,3 +122,36 @@ def test_no_cpu_fallback():
     with pytest.raises(jirf_hip.JirfError) as e:
         net.finalize()
     assert e.value.code == -6
+
+
+def test_astv2_and_ast_key_layouts():
+    from oracle import ast_oracle, astv2_oracle
+    from oracle.weights import make_ast_state, make_astv2_state
+    specs = dict(jirf_hip.Net("ASTv2", astv2_oracle.default_config()).param_specs())
+    sd = make_astv2_state()
+    assert set(specs) == set(sd) and all(tuple(specs[k]) == sd[k].shape for k in sd)
+    assert specs["decoder_level3.0.attn.att_ca.weight"] == (48, 24, 1, 1)          # 2ch x ch, ch = 192 / 8
+    assert specs["encoder_level1.0.ffn.partial_conv3.weight"] == (2, 1, 3, 3)       # dim // 24
+    assert specs["decoder_level1.0.attn.temperature"] == (2, 1, 1)
+
+    specs = dict(jirf_hip.Net("AST", ast_oracle.default_config()).param_specs())
+    sd = make_ast_state()
+    buffers = {k for k in sd if k.endswith("relative_position_index")}
+    assert set(specs) == set(sd) - buffers and all(tuple(specs[k]) == sd[k].shape for k in specs)
+    assert sum(int(np.prod(s)) for s in specs.values()) == 26339347 - 10 * 64 * 64  # ~26.3 M parameters
+    assert specs["conv.blocks.0.attn.relative_position_bias_table"] == (225, 16)
+    assert specs["upsample_1.deconv.0.weight"] == (512, 128, 2, 2)
+    assert specs["dowsample_0.conv.0.weight"] == (64, 32, 4, 4)
+    assert "encoderlayer_0.blocks.0.norm1.weight" not in specs                      # att=False blocks
+    net = jirf_hip.Net("AST", ast_oracle.default_config())
+    net.set_param("conv.blocks.0.attn.relative_position_index", np.zeros((64, 64), np.int32))   # accepted, recomputed
+
+
+def test_ast_constructor_contract():
+    from basicsr.models.archs import define_network
+    net = define_network(dict(type="AST", token_mlp="frfn", some_unknown_option=1))   # **kwargs is swallowed
+    assert type(net).__name__ == "AST"
+    with pytest.raises(NotImplementedError):
+        define_network(dict(type="AST"))                                              # default token_mlp="leff"
+    with pytest.raises(TypeError):
+        define_network(dict(type="ASTv2", some_unknown_option=1))                     # no **kwargs there
