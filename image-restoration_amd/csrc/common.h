@@ -107,6 +107,8 @@ struct GemmArgs {
 };
 
 void launch_gemm(const GemmArgs& a, int loader, hipStream_t s);
+// true when the LD_LN loader computes the LayerNorm statistics itself (mu / rstd may be null)
+bool gemm_ln_inline(int K);
 // host-side packers (return Kpad; out is resized to Kpad * Mpad)
 int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad);
 int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad);

@@ -13,6 +13,7 @@
 // staged through registers so the loader can mask, gather, normalise (LayerNorm folded into the
 // load) or shift (3x3 taps).  The 96-row tile exists because every channel count of the
 // Restormer-family nets is 48 * 2^k: 96, 192, 288, 384, 576, 1152 are all multiples of 96.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -32,6 +33,81 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   const int xcd = id & 7, local = id >> 3;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + local;
+}
+
+// Epilogue of one 32 x 32 accumulator tile: rows row0 + (r & 3) + 8 * (r >> 2) (row0 already holds
+// the lane half's + 4), column `col` (< P).  Everything the epilogue reads is gathered first so
+// the 16 loads are in flight together — output and residual may be the same buffer, which keeps
+// the compiler from hoisting them itself — then combined and stored.
+template <int EPI>
+__device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x16& acc, int row0,
+                                           int col, const float* bias_r) {
+  const int M = a.M, P = a.P;
+  float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
+  float aux[16];
+  if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL) {
+    const float* __restrict__ rp = a.r.p + (long)b * a.r.bs + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2);
+      aux[r] = row < M ? rp[(long)row * P] : 0.f;
+    }
+  }
+  if constexpr (EPI == EP_AV_INTRA) {
+    const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
+    const float* __restrict__ qp = a.q.p + (long)b * a.q.bs + col;
+    const float* __restrict__ kp = a.k.p + (long)b * a.k.bs + col;
+    int src[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2);
+      src[r] = row < M ? perm[row] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      aux[r] = qp[(long)src[r] * P] * a.rq[(long)b * M + src[r]] +
+               kp[(long)src[r] * P] * a.rk[(long)b * M + src[r]];
+  }
+  int py = 0, px = 0;
+  if constexpr (EPI == EP_UNSHUFFLE || EPI == EP_SHUFFLE) {
+    py = col / a.W;
+    px = col - py * a.W;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2);
+    if (row >= M) continue;
+    const float v = acc[r] + bias_r[r];
+    if constexpr (EPI == EP_STORE) {
+      yb[(long)row * P + col] = v;
+    } else if constexpr (EPI == EP_RESID) {
+      yb[(long)row * P + col] = v + aux[r];
+    } else if constexpr (EPI == EP_GELU_MUL) {
+      yb[(long)row * P + col] = gelu_erf(v) * aux[r];
+    } else if constexpr (EPI == EP_GELU) {
+      yb[(long)row * P + col] = gelu_erf(v);
+    } else if constexpr (EPI == EP_LEAKY) {
+      yb[(long)row * P + col] = v > 0.f ? v : 0.01f * v;
+    } else if constexpr (EPI == EP_AV_INTRA) {
+      yb[(long)row * P + col] = v;
+      a.y2.p[(long)b * a.y2.bs + (long)row * P + col] = v + aux[r];
+    } else if constexpr (EPI == EP_UNSHUFFLE) {
+      const int oc = 4 * row + 2 * (py & 1) + (px & 1);
+      yb[(long)oc * (P >> 2) + (long)(py >> 1) * (a.W >> 1) + (px >> 1)] = v;
+    } else if constexpr (EPI == EP_SHUFFLE) {
+      const int oc = row >> 2;
+      const int oy = 2 * py + ((row >> 1) & 1), ox = 2 * px + (row & 1);
+      yb[(long)oc * (4L * P) + (long)oy * (2 * a.W) + ox] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void load_bias16(const GemmArgs& a, int row0, float* bias_r) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2);
+    bias_r[r] = (a.bias && row < a.M) ? a.bias[row] : 0.f;
+  }
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int LOADER, bool VEC>
@@ -232,82 +308,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
-  // Per 32 x 32 accumulator tile: first gather everything the epilogue reads (so the 16 loads
-  // are in flight together — output and residual may be the same buffer, which keeps the
-  // compiler from hoisting them itself), then combine and store.
-  const int M = a.M;
-  float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
   auto run_epilogue = [&](auto epi_tag) {
     constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row0 = m0 + wm * WM + i * 32 + 4 * half;
       float bias_r[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        bias_r[r] = (a.bias && row < M) ? a.bias[row] : 0.f;
-      }
+      load_bias16(a, row0, bias_r);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WN + j * 32 + l31;
-        if (col >= P) continue;
-        float aux[16];
-        if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL) {
-          const float* __restrict__ rp = a.r.p + (long)b * a.r.bs + col;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2);
-            aux[r] = row < M ? rp[(long)row * P] : 0.f;
-          }
-        }
-        if constexpr (EPI == EP_AV_INTRA) {
-          const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
-          const float* __restrict__ qp = a.q.p + (long)b * a.q.bs + col;
-          const float* __restrict__ kp = a.k.p + (long)b * a.k.bs + col;
-          int src[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2);
-            src[r] = row < M ? perm[row] : 0;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            aux[r] = qp[(long)src[r] * P] * a.rq[(long)b * M + src[r]] +
-                     kp[(long)src[r] * P] * a.rk[(long)b * M + src[r]];
-        }
-        int py = 0, px = 0;
-        if constexpr (EPI == EP_UNSHUFFLE || EPI == EP_SHUFFLE) {
-          py = col / a.W;
-          px = col - py * a.W;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + (r & 3) + 8 * (r >> 2);
-          if (row >= M) continue;
-          const float v = acc[i][j][r] + bias_r[r];
-          if constexpr (EPI == EP_STORE) {
-            yb[(long)row * P + col] = v;
-          } else if constexpr (EPI == EP_RESID) {
-            yb[(long)row * P + col] = v + aux[r];
-          } else if constexpr (EPI == EP_GELU_MUL) {
-            yb[(long)row * P + col] = gelu_erf(v) * aux[r];
-          } else if constexpr (EPI == EP_GELU) {
-            yb[(long)row * P + col] = gelu_erf(v);
-          } else if constexpr (EPI == EP_LEAKY) {
-            yb[(long)row * P + col] = v > 0.f ? v : 0.01f * v;
-          } else if constexpr (EPI == EP_AV_INTRA) {
-            yb[(long)row * P + col] = v;
-            a.y2.p[(long)b * a.y2.bs + (long)row * P + col] = v + aux[r];
-          } else if constexpr (EPI == EP_UNSHUFFLE) {
-            const int oc = 4 * row + 2 * (py & 1) + (px & 1);
-            yb[(long)oc * (P >> 2) + (long)(py >> 1) * (a.W >> 1) + (px >> 1)] = v;
-          } else if constexpr (EPI == EP_SHUFFLE) {
-            const int oc = row >> 2;
-            const int oy = 2 * py + ((row >> 1) & 1), ox = 2 * px + (row & 1);
-            yb[(long)oc * (4L * P) + (long)oy * (2 * a.W) + ox] = v;
-          }
-        }
+        if (col < P) store_tile<EPI>(a, b, acc[i][j], row0, col, bias_r);
       }
     }
   };
@@ -330,6 +341,212 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
     else if (epi == EP_SHUFFLE) run_epilogue(std::integral_constant<int, EP_SHUFFLE>{});
     else run_epilogue(std::integral_constant<int, EP_STORE>{});
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Activation-stationary form for short reductions (K <= 256), which is every 1x1 conv of the full
+// resolution levels.  The workgroup loads its whole [K][BN] activation tile into LDS once (gather,
+// split source or LayerNorm applied on the way; LayerNorm statistics are computed from the tile
+// itself, so no separate statistics pass exists), then each wave walks over 32-row output tiles:
+// A fragments come straight from the K-major packed weights in L2 (128-byte rows), B fragments from
+// LDS, and the stores of one output tile overlap the MFMAs of the next.  No barrier after the load.
+// ------------------------------------------------------------------------------------------------
+constexpr int XS_ABATCH = 8;  // k-steps of A fragments fetched ahead
+
+template <int BN, int TNW, int LOADER, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float xs_smem[];
+  constexpr int NG = BN / (32 * TNW);  // pixel groups a wave can own
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / tiles_n;
+  const int n0 = (blockIdx.x - b * tiles_n) * BN;
+  const int K = a.K, P = a.P, M = a.M;
+  // K rounded up like the packed weights (zero rows there, zero rows here): the k loop then runs
+  // in whole batches with no tail and no predicated load
+  const int Kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  float* __restrict__ Xs = xs_smem;                  // [Kp][BN]
+  float* __restrict__ st_mu = xs_smem + Kp * BN;     // [BN] (LD_LN)
+  float* __restrict__ st_rs = st_mu + BN;
+  const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
+  const int* __restrict__ kidx = nullptr;
+  if constexpr (LOADER == LD_GATHER) kidx = a.kidx + (long)(b / a.imgs_per_group) * K;
+
+  // ---- load the tile --------------------------------------------------------------------------
+  for (int s = tid; s < Kp * (BN / 4); s += 256) {
+    const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+    const int p = n0 + c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K && p < P) {
+      int row = k;
+      if constexpr (LOADER == LD_GATHER) row = kidx[k];
+      const float* __restrict__ src = xb + (long)row * P + p;
+      if constexpr (LOADER == LD_PLAIN) {
+        if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)row * P + p;
+      }
+      if constexpr (VEC) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = src[0];
+        if (p + 1 < P) v.y = src[1];
+        if (p + 2 < P) v.z = src[2];
+        if (p + 3 < P) v.w = src[3];
+      }
+    }
+    *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
+  }
+  __syncthreads();
+  if constexpr (LOADER == LD_LN) {
+    // per-pixel mean and population variance over the K channels (two passes, as the reference's
+    // mean / var(unbiased=False)); columns past the image stay zero
+    if (tid < BN) {
+      float sum = 0.f;
+      for (int k = 0; k < K; ++k) sum += Xs[k * BN + tid];
+      const float mu = sum / (float)K;
+      float var = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float d = Xs[k * BN + tid] - mu;
+        var = fmaf(d, d, var);
+      }
+      st_mu[tid] = a.ln_center ? mu : 0.f;
+      st_rs[tid] = n0 + tid < P ? 1.0f / sqrtf(var / (float)K + 1e-5f) : 0.f;
+    }
+    __syncthreads();
+    for (int s = tid; s < K * (BN / 4); s += 256) {
+      const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+      const float g = a.lnw[k];
+      const float be = a.lnb ? a.lnb[k] : 0.f;
+      float4 v = *reinterpret_cast<float4*>(&Xs[k * BN + c4]);
+      const float4 mu = *reinterpret_cast<const float4*>(&st_mu[c4]);
+      const float4 rs = *reinterpret_cast<const float4*>(&st_rs[c4]);
+      const int p = n0 + c4;
+      v.x = p < P ? (v.x - mu.x) * rs.x * g + be : 0.f;
+      v.y = p + 1 < P ? (v.y - mu.y) * rs.y * g + be : 0.f;
+      v.z = p + 2 < P ? (v.z - mu.z) * rs.z * g + be : 0.f;
+      v.w = p + 3 < P ? (v.w - mu.w) * rs.w * g + be : 0.f;
+      *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
+    }
+    __syncthreads();
+  }
+
+  // ---- output tiles -----------------------------------------------------------------------------
+  const float* __restrict__ wt = a.wt + (long)b * a.wt_bs;
+  const int n_mt = (M + 31) >> 5;
+  const int n_items = n_mt * NG;
+  const int nsteps = Kp >> 1;
+  const int epi = a.epi;
+  // A-fragment address of an item: rows past Mpad do not exist in the packed weights, so the
+  // column is clamped (results of such rows are never stored)
+  auto a_ptr = [&](int item) {
+    const int m0 = (item / NG) * 32;
+    return wt + (long)half * a.Mpad + min(m0 + l31, a.Mpad - 1);
+  };
+  // nsteps is a multiple of XS_ABATCH (K is padded to 16): every load below is unconditional, and
+  // the batch fetched during an item's last batch already belongs to the wave's next item
+  float a_cur[XS_ABATCH], a_nxt[XS_ABATCH];
+  if (wave < n_items) {
+    const float* __restrict__ ap0 = a_ptr(wave);
+#pragma unroll
+    for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = ap0[(long)(2 * i) * a.Mpad];
+  }
+  for (int item = wave; item < n_items; item += 4) {
+    const int mt = item / NG, ng = item - mt * NG;
+    const int m0 = mt * 32;
+    const int col_w = ng * TNW * 32;            // first pixel of this wave's group inside the tile
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float* __restrict__ ap = a_ptr(item);
+    const float* __restrict__ ap_next = a_ptr(item + 4 < n_items ? item + 4 : item);
+    const float* __restrict__ bp = Xs + half * BN + col_w + l31;
+    for (int s0 = 0; s0 < nsteps; s0 += XS_ABATCH) {
+      const bool last = s0 + XS_ABATCH >= nsteps;
+      const float* __restrict__ src = last ? ap_next : ap + (long)(2 * (s0 + XS_ABATCH)) * a.Mpad;
+#pragma unroll
+      for (int i = 0; i < XS_ABATCH; ++i) a_nxt[i] = src[(long)(2 * i) * a.Mpad];
+#pragma unroll
+      for (int i = 0; i < XS_ABATCH; ++i) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], bp[(2 * (s0 + i)) * BN + j * 32], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = a_nxt[i];
+    }
+    const int row0 = m0 + 4 * half;
+    float bias_r[16];
+    load_bias16(a, row0, bias_r);
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int col = n0 + col_w + j * 32 + l31;
+      if (col >= P) continue;
+      if constexpr (LOADER == LD_GATHER) {
+        store_tile<EP_AV_INTRA>(a, b, acc[j], row0, col, bias_r);
+      } else if constexpr (LOADER == LD_LN) {
+        store_tile<EP_STORE>(a, b, acc[j], row0, col, bias_r);
+      } else {
+        if (epi == EP_RESID) store_tile<EP_RESID>(a, b, acc[j], row0, col, bias_r);
+        else if (epi == EP_GELU_MUL) store_tile<EP_GELU_MUL>(a, b, acc[j], row0, col, bias_r);
+        else if (epi == EP_GELU) store_tile<EP_GELU>(a, b, acc[j], row0, col, bias_r);
+        else if (epi == EP_SHUFFLE) store_tile<EP_SHUFFLE>(a, b, acc[j], row0, col, bias_r);
+        else store_tile<EP_STORE>(a, b, acc[j], row0, col, bias_r);
+      }
+    }
+  }
+}
+
+static bool xs_enabled() {
+  static const bool on = !std::getenv("JIRF_GEMM_NO_XS") && !std::getenv("JIRF_GEMM_TILE");
+  return on;
+}
+bool gemm_ln_inline(int K) { return K <= 256 && xs_enabled(); }
+
+template <int BN, int TNW>
+static void launch_xs(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
+  const int tiles_n = (a.P + BN - 1) / BN;
+  const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  const size_t smem = ((size_t)Kp * BN + 2 * BN) * sizeof(float);
+  const dim3 grid((unsigned)(tiles_n * a.B)), block(256);
+#define JIRF_XS_CASE(LD, V)                                                                        \
+  do {                                                                                             \
+    static bool attr = false;                                                                      \
+    if (!attr) {                                                                                   \
+      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_xs_kernel<BN, TNW, LD, V>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));  \
+      attr = true;                                                                                 \
+    }                                                                                              \
+    hipLaunchKernelGGL((gemm_xs_kernel<BN, TNW, LD, V>), grid, block, smem, s, a, tiles_n);        \
+  } while (0)
+  switch (loader) {
+    case LD_PLAIN:
+      if (vec) JIRF_XS_CASE(LD_PLAIN, true); else JIRF_XS_CASE(LD_PLAIN, false);
+      break;
+    case LD_GATHER:
+      if (vec) JIRF_XS_CASE(LD_GATHER, true); else JIRF_XS_CASE(LD_GATHER, false);
+      break;
+    case LD_LN:
+      if (vec) JIRF_XS_CASE(LD_LN, true); else JIRF_XS_CASE(LD_LN, false);
+      break;
+    default:
+      JIRF_REQUIRE(false, JIRF_EINVAL, "launch_xs: loader %d", loader);
+  }
+#undef JIRF_XS_CASE
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+template <int BN>
+static void launch_xs_bn(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
+  // pixel groups per output-row tile: keep the four waves evenly loaded
+  const int n_mt = (a.M + 31) / 32;
+  constexpr int TN = BN / 32;
+  if (n_mt % 4 == 0 || n_mt >= 12)
+    launch_xs<BN, TN>(a, loader, vec, s);
+  else if ((n_mt * 2) % 4 == 0 || n_mt * 2 >= 12)
+    launch_xs<BN, TN / 2>(a, loader, vec, s);
+  else
+    launch_xs<BN, 1>(a, loader, vec, s);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -401,19 +618,36 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   if (a.epi == EP_AV_INTRA) bytes += 4.0 * a.B * (double)a.P * a.M * 3;
   Scope sc(intern_label("%s M%d K%d P%d", name, a.M, a.K, a.P), flops, bytes, s);
 
-  // Tile choice: least padded rows first (MFMA work is wasted on padding), then the largest tile
-  // that still gives every CU at least two workgroups.
+  // Kernel choice, from per-shape measurements on MI355X (HINT / ASTv2 / AST shapes, B = 16):
+  //  * activation-stationary kernel when LayerNorm rides on the load (it also replaces the
+  //    statistics pass) and for plain loads with a short K and a tall M (each loaded tile then feeds
+  //    a long MFMA phase);
+  //  * otherwise the K-loop kernel, by default with its smallest 64 x 64 tile: 7 waves per SIMD hide
+  //    the load / store phases of these bandwidth-heavy shapes better than bigger tiles do;
+  //  * 128 x 128 only where the reduction is long and the output tall (MFMA-bound shapes),
+  //    96 x 128 for M = 96 with K > 128.
+  static const int forced = std::getenv("JIRF_GEMM_TILE") ? std::atoi(std::getenv("JIRF_GEMM_TILE")) : -1;
+  const bool xs = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
+                  (loader == LD_LN || (a.K <= 128 && a.M >= 4 * a.K));
+  if (xs) {
+    if (a.K <= 128) launch_xs_bn<128>(a, loader, vec, s);
+    else launch_xs_bn<64>(a, loader, vec, s);
+    return;
+  }
+  if (loader == LD_LN)
+    JIRF_REQUIRE(a.mu && a.rstd, JIRF_EINVAL, "launch_gemm: LayerNorm statistics are needed for K=%d", a.K);
   auto blocks = [&](int bm, int bn) {
     return (long)((a.M + bm - 1) / bm) * ((a.P + bn - 1) / bn) * a.B;
   };
   auto padded = [&](int bm) { return (a.M + bm - 1) / bm * bm; };
-  const int pad128 = padded(128), pad96 = padded(96), pad64 = padded(64);
-  if (pad96 < pad128 && pad96 <= pad64 && blocks(96, 128) >= 512)
-    launch_tile<3, 1, 1, 4>(a, loader, vec, s);
-  else if (pad128 <= pad64 && blocks(128, 128) >= 512)
+  if (forced == 0) return launch_tile<3, 1, 1, 4>(a, loader, vec, s);
+  if (forced == 1) return launch_tile<2, 2, 2, 2>(a, loader, vec, s);
+  if (forced == 2) return launch_tile<2, 2, 1, 2>(a, loader, vec, s);
+  if (forced == 3) return launch_tile<2, 2, 1, 1>(a, loader, vec, s);
+  if (a.K >= 192 && (a.M >= 768 || a.K >= 1024) && a.M >= 384 && blocks(128, 128) >= 512)
     launch_tile<2, 2, 2, 2>(a, loader, vec, s);
-  else if (blocks(64, 128) >= 512)
-    launch_tile<2, 2, 1, 2>(a, loader, vec, s);
+  else if (padded(96) < padded(64) && a.K > 128 && blocks(96, 128) >= 512)
+    launch_tile<3, 1, 1, 4>(a, loader, vec, s);
   else
     launch_tile<2, 2, 1, 1>(a, loader, vec, s);
 }

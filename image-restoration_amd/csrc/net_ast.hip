@@ -293,7 +293,7 @@ class AstNet final : public Net {
     const TV t1 = tv(t1_, (long)t1_per_), t2 = tv(t2_, (long)t2_per_);
     if (bl.att) {
       // norm1 -> fused q|k|v projection -> window attention -> proj + shortcut
-      launch_ln_stats(x, mu_, rstd_, B, C, P, s);
+      if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
       GemmArgs g{};
       g.B = B; g.M = 3 * C; g.K = C; g.P = P; g.Mpad = bl.qkv.Mpad; g.wt = bl.qkv.wt; g.bias = bl.qkv.bias;
       g.x = x; g.y = t1; g.epi = EP_STORE; g.imgs_per_group = 1;
