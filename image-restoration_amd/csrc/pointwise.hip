@@ -3,6 +3,8 @@
 //
 // Activations are planar [channel][pixel]; a wave's 64 lanes always sit on 64 (or 256) adjacent
 // pixels, so every global access is a full 256-B / 1-KiB row segment.
+#include <algorithm>
+
 #include "common.h"
 
 namespace jirf {
@@ -181,6 +183,121 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   }
 }
 
+// Register-rolling form used whenever rows are float4-addressable (W % 4 == 0, aligned planes):
+// a lane owns 4 adjacent pixels and walks down R output rows keeping three input rows in
+// registers; the left / right neighbours come from the adjacent lanes (__shfl), only the lanes on
+// a tile edge touch memory for them.  One wave per task, no LDS, no barrier; every global access
+// is a 16-byte lane access on a contiguous row segment.
+template <int MODE>
+__global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ y, long y_bs, int C,
+                                                             int H, int W, int lx_log2, int R,
+                                                             int tiles_x, int strips, int n_tasks,
+                                                             int wmod, int wconv) {
+  constexpr int NP = MODE == 0 ? 1 : 2;
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= n_tasks) return;  // whole wave
+  const int b = blockIdx.y;
+  const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
+  int t = task;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ts = t % strips;
+  const int c = t / strips;
+  const int xq = lane & (LX - 1), yr = lane >> lx_log2;
+  const int px = (tx * LX + xq) * 4;
+  const int ys = (ts * RW + yr) * R;
+  const long P = (long)H * W;
+  const int Cout = MODE == 0 ? C : C / 2;
+  const bool x_ok = px < W;
+
+  struct Row { float v[6]; };
+  auto load_row = [&](const float* __restrict__ plane, int yy) {
+    Row r;
+    const bool ok = x_ok && yy >= 0 && yy < H;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* __restrict__ p = plane + (long)yy * W + px;
+    if (ok) m = *reinterpret_cast<const float4*>(p);
+    float l = __shfl_up(m.w, 1), rr = __shfl_down(m.x, 1);
+    if (xq == 0) l = (ok && px > 0) ? p[-1] : 0.f;
+    if (xq == LX - 1 || px + 4 >= W) rr = (ok && px + 4 < W) ? p[4] : 0.f;
+    r.v[0] = l; r.v[1] = m.x; r.v[2] = m.y; r.v[3] = m.z; r.v[4] = m.w; r.v[5] = rr;
+    return r;
+  };
+
+  // per-plane state
+  float k[NP][9], bb[NP];
+  bool conv[NP];
+  const float* plane[NP];
+#pragma unroll
+  for (int g = 0; g < NP; ++g) {
+    const int ch = c + g * Cout;
+    int wch = ch;
+    conv[g] = !((MODE == 2 || MODE == 3) && g == 1);
+    if (MODE == 0 && wmod > 0) {
+      wch = ch % wmod;
+      conv[g] = wch < wconv;
+    }
+    plane[g] = x + (long)b * x_bs + (long)ch * P;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[g][i] = conv[g] ? w[wch * 9 + i] : 0.f;
+    bb[g] = (conv[g] && bias) ? bias[wch] : 0.f;
+  }
+  Row ra[NP], rb[NP], rc[NP];
+#pragma unroll
+  for (int g = 0; g < NP; ++g) {
+    ra[g] = load_row(plane[g], ys - 1);
+    rb[g] = load_row(plane[g], ys);
+  }
+  float* __restrict__ dst0 = y + (long)b * y_bs + (long)c * P + px;
+  for (int i = 0; i < R; ++i) {
+    const int oy = ys + i;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) rc[g] = load_row(plane[g], oy + 1);
+    float res[NP][4];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      if (!conv[g]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) res[g][j] = rb[g].v[1 + j];
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float acc = bb[g];
+        acc = fmaf(k[g][0], ra[g].v[j], acc);
+        acc = fmaf(k[g][1], ra[g].v[j + 1], acc);
+        acc = fmaf(k[g][2], ra[g].v[j + 2], acc);
+        acc = fmaf(k[g][3], rb[g].v[j], acc);
+        acc = fmaf(k[g][4], rb[g].v[j + 1], acc);
+        acc = fmaf(k[g][5], rb[g].v[j + 2], acc);
+        acc = fmaf(k[g][6], rc[g].v[j], acc);
+        acc = fmaf(k[g][7], rc[g].v[j + 1], acc);
+        acc = fmaf(k[g][8], rc[g].v[j + 2], acc);
+        res[g][j] = acc;
+      }
+    }
+    float4 o;
+    if constexpr (MODE == 1 || MODE == 3) {
+      o = make_float4(gelu_erf_pw(res[0][0]) * res[NP - 1][0], gelu_erf_pw(res[0][1]) * res[NP - 1][1],
+                      gelu_erf_pw(res[0][2]) * res[NP - 1][2], gelu_erf_pw(res[0][3]) * res[NP - 1][3]);
+    } else if constexpr (MODE == 2) {
+      o = make_float4(res[0][0] * res[1][0], res[0][1] * res[1][1], res[0][2] * res[1][2], res[0][3] * res[1][3]);
+    } else {
+      o = make_float4(res[0][0], res[0][1], res[0][2], res[0][3]);
+    }
+    if (x_ok && oy < H) *reinterpret_cast<float4*>(dst0 + (long)oy * W) = o;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      ra[g] = rb[g];
+      rb[g] = rc[g];
+    }
+  }
+}
+
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
                       int gate, hipStream_t s, int wmod, int wconv) {
   JIRF_REQUIRE(gate >= 0 && gate <= 3, JIRF_EINVAL, "dwconv3x3: mode %d", gate);
@@ -194,6 +311,27 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
   const char* nm = wmod ? "dwconv3x3_partial" : gate == 1 ? "dwconv3x3_gate" : gate == 2 ? "dwconv3x3_mul"
                    : gate == 3 ? "dwconv3x3_gelu_mul" : "dwconv3x3";
   Scope sc(intern_label("%s C%d H%d W%d", nm, C, H, W), 18.0 * px * (gate >= 2 ? C / 2 : C), 4.0 * px * (C + Cout), s);
+  const bool vec = W % 4 == 0 && x.bs % 4 == 0 && y.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(y.p) & 15) == 0;
+  if (vec) {
+    int lx_log2 = 0;
+    while ((1 << lx_log2) < 64 && (4 << lx_log2) < W) ++lx_log2;    // lanes across a row: up to 64 x 4 px
+    const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
+    const int R = std::max(1, std::min(8, H / RW));
+    const int tx = (W + 4 * LX - 1) / (4 * LX), strips = (H + RW * R - 1) / (RW * R);
+    const int n_tasks = tx * strips * Cout;
+    const dim3 g2((unsigned)((n_tasks + 3) / 4), B);
+#define JIRF_DW_ROWS(M, WM, WC) \
+    hipLaunchKernelGGL(dwconv3x3_rows_kernel<M>, g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W, lx_log2, R, \
+                       tx, strips, n_tasks, WM, WC)
+    if (gate == 1) JIRF_DW_ROWS(1, 0, 0);
+    else if (gate == 2) JIRF_DW_ROWS(2, 0, 0);
+    else if (gate == 3) JIRF_DW_ROWS(3, 0, 0);
+    else JIRF_DW_ROWS(0, wmod, wconv);
+#undef JIRF_DW_ROWS
+    JIRF_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (gate == 1)
     hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
                        tiles_x, tiles_y, 0, 0);
