@@ -68,11 +68,46 @@ void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, 
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
+// Statistics only, for small planes: 64 pixels per workgroup, the channels dealt over its 4 waves
+// and the partial sums combined through LDS, so a 32 x 32 plane still fills the chip.
+__global__ __launch_bounds__(256) void ln_stats_split_kernel(const float* __restrict__ x, long x_bs,
+                                                             float* __restrict__ mu_out,
+                                                             float* __restrict__ rstd_out, int C, int P) {
+  __shared__ float part[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const int b = blockIdx.y;
+  const bool ok = p < P;
+  const float* __restrict__ xp = x + (long)b * x_bs + (ok ? p : 0);
+  float s = 0.f;
+#pragma unroll 8
+  for (int c = wave; c < C; c += 4) s += xp[(long)c * P];
+  part[0][wave][lane] = s;
+  __syncthreads();
+  const float mu = (part[0][0][lane] + part[0][1][lane] + part[0][2][lane] + part[0][3][lane]) / (float)C;
+  float v = 0.f;
+#pragma unroll 8
+  for (int c = wave; c < C; c += 4) {
+    const float d = xp[(long)c * P] - mu;
+    v = fmaf(d, d, v);
+  }
+  part[1][wave][lane] = v;
+  __syncthreads();
+  if (wave == 0 && ok) {
+    v = part[1][0][lane] + part[1][1][lane] + part[1][2][lane] + part[1][3][lane];
+    mu_out[(long)b * P + p] = mu;
+    rstd_out[(long)b * P + p] = 1.0f / sqrtf(v / (float)C + 1e-5f);
+  }
+}
+
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s) {
-  const dim3 grid((P + 255) / 256, B), block(256);
   Scope sc(intern_label("ln_stats C%d P%d", C, P), 5.0 * B * (double)C * P, 4.0 * B * (double)P * (C + 2), s);
-  hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x.p, x.bs, nullptr, nullptr, nullptr,
-                     0L, mu, rstd, C, P);
+  if ((long)B * P <= 256 * 1024) {
+    hipLaunchKernelGGL(ln_stats_split_kernel, dim3((P + 63) / 64, B), dim3(256), 0, s, x.p, x.bs, mu, rstd, C, P);
+  } else {
+    hipLaunchKernelGGL(layernorm_kernel<0>, dim3((P + 255) / 256, B), dim3(256), 0, s, x.p, x.bs, nullptr,
+                       nullptr, nullptr, 0L, mu, rstd, C, P);
+  }
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
