@@ -62,6 +62,22 @@ def hint_flops_per_image(cfg, h, w):
     return total
 
 
+def pmc_traffic(label, batch):
+    """HBM bytes per launch of the kernel `label`, from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).
+    None when no pass was recorded for this launch shape and batch."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")), reverse=True):
+        with open(path) as fh:
+            rec = json.load(fh)
+        if rec.get("op", "").startswith(label + " ") and f"(B={batch})" in rec.get("op", ""):
+            ks = list(rec.get("kernels", {}).values())
+            if ks:
+                return ks[0].get("hbm_bytes_per_launch")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,19 +179,22 @@ def main():
                              f"{v['flops'] / (v['ms'] / 1e3) / 1e12 if v['ms'] else 0:7.2f} TFLOP/s  "
                              f"{v['bytes'] / (v['ms'] / 1e3) / 1e9 if v['ms'] else 0:8.1f} GB/s  {k}\n")
         tot_ms = sum(a["ms"] for a in acc.values())
-        dom = max(acc.items(), key=lambda kv: kv[1]["ms"])
-        name, a = dom
-        gemm_like = name.startswith("gemm") or name == "hint_chan_stats"
-        if gemm_like:
-            ach = a["flops"] / (a["ms"] / 1e3) / 1e12
+        # the dominant kernel = the single launch shape with the largest share of device time
+        name, a = max(detail.items(), key=lambda kv: kv[1]["ms"])
+        family = name.split(" ")[0]
+        per_launch_s = a["ms"] / 1e3 / a["launches"]
+        if family.startswith("gemm") or family == "hint_chan_stats":
+            ach = a["flops"] / a["launches"] / per_launch_s / 1e12
             roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
         else:
-            ach = a["bytes"] / (a["ms"] / 1e3) / 1e9
+            ach = a["bytes"] / a["launches"] / per_launch_s / 1e9
             roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-        roof.update({"traffic": None, "launches_per_step": a["launches"] // args.steps,
-                     "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
+        roof.update({"traffic": pmc_traffic(name, B), "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                     "algorithmic_flops_per_launch": a["flops"] / a["launches"],
+                     "launches_per_step": a["launches"] // args.steps,
+                     "avg_launch_us": round(per_launch_s * 1e6, 2),
                      "share_of_device_time": round(a["ms"] / tot_ms, 4)})
         out["roofline"] = roof
         out["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),

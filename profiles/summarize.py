@@ -1,0 +1,70 @@
+"""Turn the rocprofv3 (rocpd sqlite) outputs of profiles/collect.sh into the small text/JSON
+summaries kept under profiles/.  Usage: python profiles/summarize.py <tag>   (reads
+gpurun_out/prof_<tag>/, writes profiles/<tag>_*)."""
+import json
+import os
+import sqlite3
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+dst = "profiles"
+
+
+def short(name):
+    return name if len(name) <= 150 else name[:147] + "..."
+
+
+# 1. kernel-trace statistics: per kernel symbol, and per (symbol, grid) so that one launch shape
+#    of a templated kernel can be read off
+db = sqlite3.connect(os.path.join(src, "trace", "bench_results.db"))
+rows = db.execute("select name, grid_x, grid_y, workgroup_x, duration from kernels").fetchall()
+by_sym, by_shape = {}, {}
+for name, gx, gy, wx, dur in rows:
+    a = by_sym.setdefault(name, [0, 0])
+    a[0] += 1
+    a[1] += dur
+    b = by_shape.setdefault((name, gx, gy, wx), [0, 0])
+    b[0] += 1
+    b[1] += dur
+total = sum(v[1] for v in by_sym.values())
+with open(os.path.join(dst, f"{tag}_hint_b16_kernel_stats.csv"), "w") as fh:
+    fh.write("kernel,calls,total_ns,avg_ns,percent\n")
+    for k, (n, t) in sorted(by_sym.items(), key=lambda kv: -kv[1][1]):
+        fh.write(f"\"{short(k)}\",{n},{t},{t / n:.0f},{100.0 * t / total:.2f}\n")
+with open(os.path.join(dst, f"{tag}_hint_b16_kernel_stats_by_grid.csv"), "w") as fh:
+    fh.write("kernel,grid_x,grid_y,workgroup_x,calls,total_ns,avg_ns,percent\n")
+    for (k, gx, gy, wx), (n, t) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+        fh.write(f"\"{short(k)}\",{gx},{gy},{wx},{n},{t},{t / n:.0f},{100.0 * t / total:.2f}\n")
+
+# 2. PMC passes over the dominant launch shape alone (profiles/pmc_op.py).
+#    FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts wide streaming
+#    reads at half their size, so reads are doubled (writes are exact).
+out = {}
+for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    p = os.path.join(src, which, "pmc_results.db")
+    if not os.path.exists(p):
+        continue
+    d = sqlite3.connect(p)
+    q = ("select k.name, k.grid_x, e.counter_value from pmc_events e join kernels k "
+         "on e.dispatch_id = k.dispatch_id where e.counter_name = ?")
+    acc = {}
+    for name, gx, val in d.execute(q, (counter,)):
+        a = acc.setdefault((name, gx), [0, 0.0])
+        a[0] += 1
+        a[1] += val
+    for (name, gx), (n, v) in acc.items():
+        if "gemm" not in name:
+            continue
+        o = out.setdefault(short(name), {"grid_x": gx, "launches": n})
+        o[counter + "_KiB_per_launch"] = v / n
+for o in out.values():
+    rd = 2.0 * 1024.0 * o.get("FETCH_SIZE_KiB_per_launch", 0.0)
+    wr = 1024.0 * o.get("WRITE_SIZE_KiB_per_launch", 0.0)
+    o.update({"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr})
+res = {"op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
+       "algorithmic_bytes_per_launch": 4.0 * 16 * 65536 * (96 + 510),
+       "kernels": out}
+with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
+    json.dump(res, fh, indent=1)
+print(json.dumps(res, indent=1))
