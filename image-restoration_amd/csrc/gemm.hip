@@ -39,7 +39,10 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // the lane half's + 4), column `col` (< P).  Everything the epilogue reads is gathered first so
 // the 16 loads are in flight together — output and residual may be the same buffer, which keeps
 // the compiler from hoisting them itself — then combined and stored.
-template <int EPI>
+// FULL: the caller has checked (wave-uniformly) that all 32 rows are < M and all 32 columns < P, so
+// nothing below is predicated — per-row predicates make the compiler branch around every store and
+// drain the memory counter in front of each one, which serialises the stores.
+template <int EPI, bool FULL>
 __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x16& acc, int row0,
                                            int col, const float* bias_r) {
   const int M = a.M, P = a.P;
@@ -50,7 +53,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + (r & 3) + 8 * (r >> 2);
-      aux[r] = row < M ? rp[(long)row * P] : 0.f;
+      aux[r] = (FULL || row < M) ? rp[(long)row * P] : 0.f;
     }
   }
   if constexpr (EPI == EP_AV_INTRA) {
@@ -61,7 +64,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + (r & 3) + 8 * (r >> 2);
-      src[r] = row < M ? perm[row] : 0;
+      src[r] = (FULL || row < M) ? perm[row] : 0;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -76,7 +79,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row0 + (r & 3) + 8 * (r >> 2);
-    if (row >= M) continue;
+    if (!FULL && row >= M) continue;
     const float v = acc[r] + bias_r[r];
     if constexpr (EPI == EP_STORE) {
       yb[(long)row * P + col] = v;
@@ -102,11 +105,22 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
   }
 }
 
+template <bool FULL>
 __device__ __forceinline__ void load_bias16(const GemmArgs& a, int row0, float* bias_r) {
+  if constexpr (FULL) {
+    if (a.bias) {   // kernel argument: a scalar branch around 16 unconditional loads
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = row0 + (r & 3) + 8 * (r >> 2);
-    bias_r[r] = (a.bias && row < a.M) ? a.bias[row] : 0.f;
+      for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[row0 + (r & 3) + 8 * (r >> 2)];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2);
+      bias_r[r] = (a.bias && row < a.M) ? a.bias[row] : 0.f;
+    }
   }
 }
 
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, half = lane >> 5;
 
@@ -312,13 +326,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
     constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int row0 = m0 + wm * WM + i * 32 + 4 * half;
+      const int rbase = m0 + wm * WM + i * 32;
+      const int row0 = rbase + 4 * half;
       float bias_r[16];
-      load_bias16(a, row0, bias_r);
+      if (rbase + 32 <= a.M) {
+        load_bias16<true>(a, row0, bias_r);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + j * 32 + l31;
-        if (col < P) store_tile<EPI>(a, b, acc[i][j], row0, col, bias_r);
+        for (int j = 0; j < TN; ++j) {
+          const int cbase = n0 + wn * WN + j * 32;
+          if (cbase + 32 <= P) store_tile<EPI, true>(a, b, acc[i][j], row0, cbase + l31, bias_r);
+          else if (cbase + l31 < P) store_tile<EPI, false>(a, b, acc[i][j], row0, cbase + l31, bias_r);
+        }
+      } else {
+        load_bias16<false>(a, row0, bias_r);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + wn * WN + j * 32 + l31;
+          if (col < P) store_tile<EPI, false>(a, b, acc[i][j], row0, col, bias_r);
+        }
       }
     }
   };
@@ -357,7 +382,7 @@ template <int BN, int TNW, int LOADER, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float xs_smem[];
   constexpr int NG = BN / (32 * TNW);  // pixel groups a wave can own
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.x / tiles_n;
   const int n0 = (blockIdx.x - b * tiles_n) * BN;
@@ -477,23 +502,28 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
     }
     const int row0 = m0 + 4 * half;
     float bias_r[16];
-    load_bias16(a, row0, bias_r);
+    auto store_all = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      load_bias16<FULL>(a, row0, bias_r);
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) {
-      const int col = n0 + col_w + j * 32 + l31;
-      if (col >= P) continue;
-      if constexpr (LOADER == LD_GATHER) {
-        store_tile<EP_AV_INTRA>(a, b, acc[j], row0, col, bias_r);
-      } else if constexpr (LOADER == LD_LN) {
-        store_tile<EP_STORE>(a, b, acc[j], row0, col, bias_r);
-      } else {
-        if (epi == EP_RESID) store_tile<EP_RESID>(a, b, acc[j], row0, col, bias_r);
-        else if (epi == EP_GELU_MUL) store_tile<EP_GELU_MUL>(a, b, acc[j], row0, col, bias_r);
-        else if (epi == EP_GELU) store_tile<EP_GELU>(a, b, acc[j], row0, col, bias_r);
-        else if (epi == EP_SHUFFLE) store_tile<EP_SHUFFLE>(a, b, acc[j], row0, col, bias_r);
-        else store_tile<EP_STORE>(a, b, acc[j], row0, col, bias_r);
+      for (int j = 0; j < TNW; ++j) {
+        const int col = n0 + col_w + j * 32 + l31;
+        if (!FULL && col >= P) continue;
+        if constexpr (LOADER == LD_GATHER) {
+          store_tile<EP_AV_INTRA, FULL>(a, b, acc[j], row0, col, bias_r);
+        } else if constexpr (LOADER == LD_LN) {
+          store_tile<EP_STORE, FULL>(a, b, acc[j], row0, col, bias_r);
+        } else {
+          if (epi == EP_RESID) store_tile<EP_RESID, FULL>(a, b, acc[j], row0, col, bias_r);
+          else if (epi == EP_GELU_MUL) store_tile<EP_GELU_MUL, FULL>(a, b, acc[j], row0, col, bias_r);
+          else if (epi == EP_GELU) store_tile<EP_GELU, FULL>(a, b, acc[j], row0, col, bias_r);
+          else if (epi == EP_SHUFFLE) store_tile<EP_SHUFFLE, FULL>(a, b, acc[j], row0, col, bias_r);
+          else store_tile<EP_STORE, FULL>(a, b, acc[j], row0, col, bias_r);
+        }
       }
-    }
+    };
+    if (m0 + 32 <= M && n0 + BN <= P) store_all(std::true_type{});
+    else store_all(std::false_type{});
   }
 }
 
