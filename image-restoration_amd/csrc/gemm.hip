@@ -39,32 +39,49 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // the lane half's + 4), column `col` (< P).  Everything the epilogue reads is gathered first so
 // the 16 loads are in flight together — output and residual may be the same buffer, which keeps
 // the compiler from hoisting them itself — then combined and stored.
-// FULL: the caller has checked (wave-uniformly) that all 32 rows are < M and all 32 columns < P, so
-// nothing below is predicated — per-row predicates make the compiler branch around every store and
-// drain the memory counter in front of each one, which serialises the stores.
-template <int EPI, bool FULL>
-__device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x16& acc, int row0,
-                                           int col, const float* bias_r) {
+// MODE ST_FULL: the caller has checked (wave-uniformly) that all 32 rows are < M and all 32 columns
+// < P, so nothing is predicated.  A predicated load makes the compiler branch around it and drain
+// the memory counter at each join, which serialises the stores behind one another; for partial
+// tiles ST_CLAMP therefore loads from clamped (always valid) addresses and predicates only the
+// stores, at the cost of ~16 more registers; ST_PRED is the compact predicated form for kernels
+// whose occupancy those registers would lower (partial tiles are the minority there).
+enum { ST_FULL = 0, ST_CLAMP = 1, ST_PRED = 2 };
+// Addresses are formed as (wave-uniform row pointer) + (32-bit lane offset): the row pointers live
+// in scalar registers and one vector register holds the lane part for all 16 rows, instead of a
+// 64-bit vector address per row.  rbase (multiple of 32, wave-uniform) is the tile's first row;
+// lane half h owns rows rbase + (r & 3) + 8 * (r >> 2) + 4 h.
+template <int EPI, int MODE>
+__device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x16& acc, int rbase,
+                                           int half, int col_in, const float* bias_r) {
+  constexpr bool FULL = MODE == ST_FULL;
   const int M = a.M, P = a.P;
+  const bool col_ok = FULL || col_in < P;
+  if (MODE == ST_PRED && !col_ok) return;
+  const unsigned voff = (unsigned)(4 * half) * (unsigned)P + (unsigned)col_in;
+  auto urow = [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); };
+  auto lane_ok = [&](int r) { return FULL || (col_ok && urow(r) + 4 * half < M); };
+  auto row_ptr = [&](auto* base, int r) { return base + (long)(FULL ? urow(r) : min(urow(r), M - 1)) * P; };
   float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
   float aux[16];
   if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL) {
-    const float* __restrict__ rp = a.r.p + (long)b * a.r.bs + col;
+    const float* __restrict__ rp = a.r.p + (long)b * a.r.bs;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2);
-      aux[r] = (FULL || row < M) ? rp[(long)row * P] : 0.f;
+      if constexpr (MODE == ST_PRED) aux[r] = lane_ok(r) ? row_ptr(rp, r)[voff] : 0.f;
+      else aux[r] = row_ptr(rp, r)[lane_ok(r) ? voff : 0u];
     }
   }
   if constexpr (EPI == EP_AV_INTRA) {
     const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
+    const int col = MODE == ST_CLAMP ? min(col_in, P - 1) : col_in;
     const float* __restrict__ qp = a.q.p + (long)b * a.q.bs + col;
     const float* __restrict__ kp = a.k.p + (long)b * a.k.bs + col;
     int src[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2);
-      src[r] = (FULL || row < M) ? perm[row] : 0;
+      const int row = urow(r) + 4 * half;
+      if constexpr (MODE == ST_PRED) src[r] = row < M ? perm[row] : 0;
+      else src[r] = perm[FULL ? row : min(row, M - 1)];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -73,31 +90,34 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
   }
   int py = 0, px = 0;
   if constexpr (EPI == EP_UNSHUFFLE || EPI == EP_SHUFFLE) {
-    py = col / a.W;
-    px = col - py * a.W;
+    py = col_in / a.W;
+    px = col_in - py * a.W;
   }
+  float* __restrict__ y2b = nullptr;
+  if constexpr (EPI == EP_AV_INTRA) y2b = a.y2.p + (long)b * a.y2.bs;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = row0 + (r & 3) + 8 * (r >> 2);
-    if (!FULL && row >= M) continue;
+    if (!lane_ok(r)) continue;
     const float v = acc[r] + bias_r[r];
     if constexpr (EPI == EP_STORE) {
-      yb[(long)row * P + col] = v;
+      row_ptr(yb, r)[voff] = v;
     } else if constexpr (EPI == EP_RESID) {
-      yb[(long)row * P + col] = v + aux[r];
+      row_ptr(yb, r)[voff] = v + aux[r];
     } else if constexpr (EPI == EP_GELU_MUL) {
-      yb[(long)row * P + col] = gelu_erf(v) * aux[r];
+      row_ptr(yb, r)[voff] = gelu_erf(v) * aux[r];
     } else if constexpr (EPI == EP_GELU) {
-      yb[(long)row * P + col] = gelu_erf(v);
+      row_ptr(yb, r)[voff] = gelu_erf(v);
     } else if constexpr (EPI == EP_LEAKY) {
-      yb[(long)row * P + col] = v > 0.f ? v : 0.01f * v;
+      row_ptr(yb, r)[voff] = v > 0.f ? v : 0.01f * v;
     } else if constexpr (EPI == EP_AV_INTRA) {
-      yb[(long)row * P + col] = v;
-      a.y2.p[(long)b * a.y2.bs + (long)row * P + col] = v + aux[r];
+      row_ptr(yb, r)[voff] = v;
+      row_ptr(y2b, r)[voff] = v + aux[r];
     } else if constexpr (EPI == EP_UNSHUFFLE) {
+      const int row = urow(r) + 4 * half;
       const int oc = 4 * row + 2 * (py & 1) + (px & 1);
       yb[(long)oc * (P >> 2) + (long)(py >> 1) * (a.W >> 1) + (px >> 1)] = v;
     } else if constexpr (EPI == EP_SHUFFLE) {
+      const int row = urow(r) + 4 * half;
       const int oc = row >> 2;
       const int oy = 2 * py + ((row >> 1) & 1), ox = 2 * px + (row & 1);
       yb[(long)oc * (4L * P) + (long)oy * (2 * a.W) + ox] = v;
@@ -105,22 +125,18 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
   }
 }
 
-template <bool FULL>
-__device__ __forceinline__ void load_bias16(const GemmArgs& a, int row0, float* bias_r) {
-  if constexpr (FULL) {
-    if (a.bias) {   // kernel argument: a scalar branch around 16 unconditional loads
+template <int MODE>
+__device__ __forceinline__ void load_bias16(const GemmArgs& a, int rbase, int half, float* bias_r) {
+  if (a.bias) {   // kernel argument: a scalar branch around the 16 loads
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[row0 + (r & 3) + 8 * (r >> 2)];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if constexpr (MODE == ST_PRED) bias_r[r] = row < a.M ? a.bias[row] : 0.f;
+      else bias_r[r] = a.bias[MODE == ST_FULL ? row : min(row, a.M - 1)];
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2);
-      bias_r[r] = (a.bias && row < a.M) ? a.bias[row] : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
   }
 }
 
@@ -327,22 +343,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rbase = m0 + wm * WM + i * 32;
-      const int row0 = rbase + 4 * half;
+      if (rbase >= a.M) continue;   // wave-uniform: a padding tile
       float bias_r[16];
       if (rbase + 32 <= a.M) {
-        load_bias16<true>(a, row0, bias_r);
+        load_bias16<ST_FULL>(a, rbase, half, bias_r);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int cbase = n0 + wn * WN + j * 32;
-          if (cbase + 32 <= P) store_tile<EPI, true>(a, b, acc[i][j], row0, cbase + l31, bias_r);
-          else if (cbase + l31 < P) store_tile<EPI, false>(a, b, acc[i][j], row0, cbase + l31, bias_r);
+          if (cbase + 32 <= P) store_tile<EPI, ST_FULL>(a, b, acc[i][j], rbase, half, cbase + l31, bias_r);
+          else if (cbase < P) store_tile<EPI, ST_PRED>(a, b, acc[i][j], rbase, half, cbase + l31, bias_r);
         }
       } else {
-        load_bias16<false>(a, row0, bias_r);
+        load_bias16<ST_PRED>(a, rbase, half, bias_r);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int col = n0 + wn * WN + j * 32 + l31;
-          if (col < P) store_tile<EPI, false>(a, b, acc[i][j], row0, col, bias_r);
+          const int cbase = n0 + wn * WN + j * 32;
+          if (cbase < P) store_tile<EPI, ST_PRED>(a, b, acc[i][j], rbase, half, cbase + l31, bias_r);
         }
       }
     }
@@ -500,25 +516,25 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
 #pragma unroll
       for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = a_nxt[i];
     }
-    const int row0 = m0 + 4 * half;
     float bias_r[16];
     auto store_all = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
-      load_bias16<FULL>(a, row0, bias_r);
+      constexpr int ST = FULL ? ST_FULL : ST_CLAMP;
+      load_bias16<ST>(a, m0, half, bias_r);
 #pragma unroll
       for (int j = 0; j < TNW; ++j) {
         const int col = n0 + col_w + j * 32 + l31;
-        if (!FULL && col >= P) continue;
+        if (!FULL && n0 + col_w + j * 32 >= P) continue;   // wave-uniform
         if constexpr (LOADER == LD_GATHER) {
-          store_tile<EP_AV_INTRA, FULL>(a, b, acc[j], row0, col, bias_r);
+          store_tile<EP_AV_INTRA, ST>(a, b, acc[j], m0, half, col, bias_r);
         } else if constexpr (LOADER == LD_LN) {
-          store_tile<EP_STORE, FULL>(a, b, acc[j], row0, col, bias_r);
+          store_tile<EP_STORE, ST>(a, b, acc[j], m0, half, col, bias_r);
         } else {
-          if (epi == EP_RESID) store_tile<EP_RESID, FULL>(a, b, acc[j], row0, col, bias_r);
-          else if (epi == EP_GELU_MUL) store_tile<EP_GELU_MUL, FULL>(a, b, acc[j], row0, col, bias_r);
-          else if (epi == EP_GELU) store_tile<EP_GELU, FULL>(a, b, acc[j], row0, col, bias_r);
-          else if (epi == EP_SHUFFLE) store_tile<EP_SHUFFLE, FULL>(a, b, acc[j], row0, col, bias_r);
-          else store_tile<EP_STORE, FULL>(a, b, acc[j], row0, col, bias_r);
+          if (epi == EP_RESID) store_tile<EP_RESID, ST>(a, b, acc[j], m0, half, col, bias_r);
+          else if (epi == EP_GELU_MUL) store_tile<EP_GELU_MUL, ST>(a, b, acc[j], m0, half, col, bias_r);
+          else if (epi == EP_GELU) store_tile<EP_GELU, ST>(a, b, acc[j], m0, half, col, bias_r);
+          else if (epi == EP_SHUFFLE) store_tile<EP_SHUFFLE, ST>(a, b, acc[j], m0, half, col, bias_r);
+          else store_tile<EP_STORE, ST>(a, b, acc[j], m0, half, col, bias_r);
         }
       }
     };
@@ -571,7 +587,8 @@ static void launch_xs_bn(const GemmArgs& a, int loader, bool vec, hipStream_t s)
   // pixel groups per output-row tile: keep the four waves evenly loaded
   const int n_mt = (a.M + 31) / 32;
   constexpr int TN = BN / 32;
-  if (n_mt % 4 == 0 || n_mt >= 12)
+  // (the attention * V epilogue is register-heavy: four accumulator tiles would spill)
+  if ((n_mt % 4 == 0 || n_mt >= 12) && loader != LD_GATHER)
     launch_xs<BN, TN>(a, loader, vec, s);
   else if ((n_mt * 2) % 4 == 0 || n_mt * 2 >= 12)
     launch_xs<BN, TN / 2>(a, loader, vec, s);
@@ -650,15 +667,15 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
 
   // Kernel choice, from per-shape measurements on MI355X (HINT / ASTv2 / AST shapes, B = 16):
   //  * activation-stationary kernel when LayerNorm rides on the load (it also replaces the
-  //    statistics pass) and for plain loads with a short K and a tall M (each loaded tile then feeds
-  //    a long MFMA phase);
+  //    statistics pass), for attention * V with K <= 128, and for plain loads with a short K and
+  //    M >= 2 K (each loaded tile then feeds a long enough MFMA phase);
   //  * otherwise the K-loop kernel, by default with its smallest 64 x 64 tile: 7 waves per SIMD hide
   //    the load / store phases of these bandwidth-heavy shapes better than bigger tiles do;
   //  * 128 x 128 only where the reduction is long and the output tall (MFMA-bound shapes),
   //    96 x 128 for M = 96 with K > 128.
   static const int forced = std::getenv("JIRF_GEMM_TILE") ? std::atoi(std::getenv("JIRF_GEMM_TILE")) : -1;
   const bool xs = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
-                  (loader == LD_LN || (a.K <= 128 && a.M >= 4 * a.K));
+                  (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
   if (xs) {
     if (a.K <= 128) launch_xs_bn<128>(a, loader, vec, s);
     else launch_xs_bn<64>(a, loader, vec, s);
