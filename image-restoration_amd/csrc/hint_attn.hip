@@ -252,6 +252,273 @@ static void launch_chan_stats(const StatsArgs& st, int nb, hipStream_t s) {
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
+// ---- 96-channel super-tile form (HINT) ------------------------------------------------------------
+// HINT's channel counts are 48 * 2^k, so 64 x 64 tiles leave a third of the matrix cores idle at
+// C = 96 and load the four waves unevenly.  Here a workgroup owns a 96 x 96 tile pair, split into
+// 3 x 3 quadrants of 32 x 32; the quadrant products (Q.K^T: fp32 MFMA, cost 1; Q.Q^T: fp64 MFMA,
+// cost 2) are dealt to the four waves greedily by cost, each wave keeping up to three of each kind
+// in registers.  Q.Q^T is symmetric: only quadrants on or above the diagonal are computed (tile
+// pairs with ti > tj compute none) and written to both (i, j) and (j, i).
+constexpr int SQ_T = 96;
+constexpr int SQ_SLOTS = 3;
+
+template <bool DO_QK, bool DO_GRAM, bool VEC>
+__global__ __launch_bounds__(256, 2) void chan_stats96_kernel(const StatsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sq_smem[];
+  constexpr int TILE = SQ_T * ST_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, quad = lane >> 4;
+  const int ti = blockIdx.x / a.tiles, tj = blockIdx.x % a.tiles;
+  const int sp = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, P = a.P;
+  const int i0 = ti * SQ_T, j0 = tj * SQ_T;
+  const bool diag = ti == tj;
+  const bool gram_on = DO_GRAM && ti <= tj;
+  if (!DO_QK && !gram_on) return;
+  const int c_begin = sp * a.chunks_per_split;
+  const int c_end = min(c_begin + a.chunks_per_split, (P + ST_CH - 1) / ST_CH);
+
+  const float* __restrict__ src_a = (DO_QK ? a.q + (long)b * a.q_bs : a.qg + (long)b * a.qg_bs);
+  const float* __restrict__ src_b = a.k + (long)b * a.k_bs;
+  const float* __restrict__ src_c = a.qg + (long)b * a.qg_bs;
+  const bool c_is_a = gram_on && diag && src_c == src_a;
+  const bool need_c = gram_on && !c_is_a;
+  float* TA = sq_smem;                          // [2][TILE]
+  float* TB = TA + 2 * TILE;                    // [2][TILE]  (DO_QK)
+  float* TC = TB + (DO_QK ? 2 * TILE : 0);      // [2][TILE]  (gram source rows of tile tj)
+
+  // ---- deal the quadrants --------------------------------------------------------------------
+  const int nr = min(3, (C - i0 + 31) >> 5), nc = min(3, (C - j0 + 31) >> 5);
+  int load[4] = {0, 0, 0, 0};
+  int gcode[SQ_SLOTS], scode[SQ_SLOTS];
+#pragma unroll
+  for (int i = 0; i < SQ_SLOTS; ++i) gcode[i] = scode[i] = -1;
+  auto least = [&]() {
+    int w = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (load[i] < load[w]) w = i;
+    return w;
+  };
+  auto give = [&](int w, int cost) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i == w) load[i] += cost;
+  };
+  auto push = [&](int* slots, int code) {
+    if (slots[0] < 0) slots[0] = code;
+    else if (slots[1] < 0) slots[1] = code;
+    else slots[2] = code;
+  };
+  if (gram_on) {
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+      const int qi = it / 3, qj = it % 3;
+      if (qi < nr && qj < nc && (!diag || qi <= qj)) {
+        const int w = least();
+        if (w == wave) push(gcode, qi * 4 + qj);
+        give(w, 2);
+      }
+    }
+  }
+  if constexpr (DO_QK) {
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+      const int qi = it / 3, qj = it % 3;
+      if (qi < nr && qj < nc) {
+        const int w = least();
+        if (w == wave) push(scode, qi * 4 + qj);
+        give(w, 1);
+      }
+    }
+  }
+
+  f32x16 s_acc[SQ_SLOTS];
+  f64x4 g_acc[SQ_SLOTS][2][2];
+#pragma unroll
+  for (int i = 0; i < SQ_SLOTS; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_acc[i][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g_acc[i][t][u][r] = 0.0;
+  }
+  double row_sum = 0.0;  // threads 0..95: sum of the gram-source row i0 + tid   (diagonal pairs)
+  float row_sq = 0.f;    // threads 0..95: sum q^2 of row i0 + tid; 96..191: sum k^2 of row j0 + tid - 96
+
+  // 96 rows x 32 px = 768 float4 slots per tile, three per thread
+  auto fetch = [&](const float* __restrict__ src, int r0, int px0, float4* out) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int sl = tid + it * 256;
+      const int row = r0 + (sl >> 3), px = px0 + (sl & 7) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < C) {
+        const float* __restrict__ ptr = src + (long)row * P + px;
+        if constexpr (VEC) {
+          if (px < P) v = *reinterpret_cast<const float4*>(ptr);
+        } else {
+          if (px < P) v.x = ptr[0];
+          if (px + 1 < P) v.y = ptr[1];
+          if (px + 2 < P) v.z = ptr[2];
+          if (px + 3 < P) v.w = ptr[3];
+        }
+      }
+      out[it] = v;
+    }
+  };
+  auto put = [&](float* dst, const float4* in) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int sl = tid + it * 256;
+      float* __restrict__ d = dst + (sl >> 3) * ST_LD + (sl & 7) * 4;
+      d[0] = in[it].x; d[1] = in[it].y; d[2] = in[it].z; d[3] = in[it].w;
+    }
+  };
+  float4 ra[3], rb[3], rc[3];
+  auto fetch_all = [&](int ch) {
+    const int px0 = ch * ST_CH;
+    fetch(src_a, i0, px0, ra);
+    if constexpr (DO_QK) fetch(src_b, j0, px0, rb);
+    if (need_c) fetch(src_c, j0, px0, rc);
+  };
+  auto put_all = [&](int buf) {
+    put(TA + buf * TILE, ra);
+    if constexpr (DO_QK) put(TB + buf * TILE, rb);
+    if (need_c) put(TC + buf * TILE, rc);
+  };
+
+  if (c_begin < c_end) {
+    fetch_all(c_begin);
+    put_all(0);
+  }
+  __syncthreads();
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int buf = (ch - c_begin) & 1;
+    if (ch + 1 < c_end) fetch_all(ch + 1);
+    const float* __restrict__ A = TA + buf * TILE;
+    const float* __restrict__ Bt = TB + buf * TILE;
+    const float* __restrict__ Ct = c_is_a ? A : TC + buf * TILE;
+    if constexpr (DO_QK) {
+#pragma unroll
+      for (int i = 0; i < SQ_SLOTS; ++i) {
+        if (scode[i] < 0) continue;
+        const float* __restrict__ ap = &A[((scode[i] >> 2) * 32 + l31) * ST_LD + half];
+        const float* __restrict__ bp = &Bt[((scode[i] & 3) * 32 + l31) * ST_LD + half];
+#pragma unroll
+        for (int k2 = 0; k2 < ST_CH / 2; ++k2)
+          s_acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * k2], bp[2 * k2], s_acc[i], 0, 0, 0);
+      }
+      if (diag && tid < 2 * SQ_T) {
+        const float* __restrict__ rowp = tid < SQ_T ? &A[tid * ST_LD] : &Bt[(tid - SQ_T) * ST_LD];
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < ST_CH; ++e) t = fmaf(rowp[e], rowp[e], t);
+        row_sq += t;
+      }
+    }
+    if (gram_on) {
+#pragma unroll
+      for (int i = 0; i < SQ_SLOTS; ++i) {
+        if (gcode[i] < 0) continue;
+        const float* __restrict__ ap = &A[((gcode[i] >> 2) * 32 + l15) * ST_LD + quad];
+        const float* __restrict__ cp = &Ct[((gcode[i] & 3) * 32 + l15) * ST_LD + quad];
+#pragma unroll
+        for (int k4 = 0; k4 < ST_CH / 4; ++k4) {
+          double av[2], bv[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            av[t] = (double)ap[t * 16 * ST_LD + 4 * k4];
+            bv[t] = (double)cp[t * 16 * ST_LD + 4 * k4];
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              g_acc[i][t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[u], g_acc[i][t][u], 0, 0, 0);
+        }
+      }
+      if (diag && tid < SQ_T) {
+        const float* __restrict__ rowp = &Ct[tid * ST_LD];
+        double t = 0.0;
+#pragma unroll
+        for (int e = 0; e < ST_CH; ++e) t += (double)rowp[e];
+        row_sum += t;
+      }
+    }
+    if (ch + 1 < c_end) put_all(buf ^ 1);
+    __syncthreads();
+  }
+
+  const long slab = ((long)b * a.splits + sp) * C;
+  if constexpr (DO_QK) {
+    float* __restrict__ out = a.qk_part + slab * C;
+#pragma unroll
+    for (int i = 0; i < SQ_SLOTS; ++i) {
+      if (scode[i] < 0) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + (scode[i] >> 2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int col = j0 + (scode[i] & 3) * 32 + l31;
+        if (row < C && col < C) out[(long)row * C + col] = s_acc[i][r];
+      }
+    }
+    if (diag && tid < SQ_T && i0 + tid < C) a.q2_part[slab + i0 + tid] = row_sq;
+    if (diag && tid >= SQ_T && tid < 2 * SQ_T && j0 + tid - SQ_T < C) a.k2_part[slab + j0 + tid - SQ_T] = row_sq;
+  }
+  if (gram_on) {
+    double* __restrict__ out = a.gram_part + slab * C;
+#pragma unroll
+    for (int i = 0; i < SQ_SLOTS; ++i) {
+      if (gcode[i] < 0) continue;
+      // quadrants off the diagonal also fill their mirror image, so the reduction reads rows
+      const bool mirror = !diag || (gcode[i] >> 2) != (gcode[i] & 3);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i0 + (gcode[i] >> 2) * 32 + t * 16 + quad + 4 * r;
+            const int col = j0 + (gcode[i] & 3) * 32 + u * 16 + l15;
+            if (row < C && col < C) {
+              out[(long)row * C + col] = g_acc[i][t][u][r];
+              if (mirror) out[(long)col * C + row] = g_acc[i][t][u][r];
+            }
+          }
+    }
+    if (diag && tid < SQ_T && i0 + tid < C) a.qsum_part[slab + i0 + tid] = row_sum;
+  }
+}
+
+template <bool DO_QK, bool DO_GRAM>
+static void launch_chan_stats96(const StatsArgs& st, int nb, hipStream_t s) {
+  auto ok = [&](const float* p, long bs) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && bs % 4 == 0; };
+  bool vec = st.P % 4 == 0;
+  if (DO_QK) vec = vec && ok(st.q, st.q_bs) && ok(st.k, st.k_bs);
+  if (DO_GRAM) vec = vec && ok(st.qg, st.qg_bs);
+  const dim3 grid(st.tiles * st.tiles, st.splits, nb), block(256);
+  // A (+ B) (+ C when a tile pair is off the diagonal or the gram source differs from q)
+  const bool need_c = DO_GRAM && (st.tiles > 1 || (DO_QK && st.qg != st.q));
+  const size_t smem = (size_t)(2 + (DO_QK ? 2 : 0) + (need_c ? 2 : 0)) * SQ_T * ST_LD * sizeof(float);
+#define JIRF_SQ_CASE(V)                                                                              \
+  do {                                                                                               \
+    static bool attr = false;                                                                        \
+    if (!attr) {                                                                                     \
+      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chan_stats96_kernel<DO_QK, DO_GRAM, V>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));    \
+      attr = true;                                                                                   \
+    }                                                                                                \
+    hipLaunchKernelGGL((chan_stats96_kernel<DO_QK, DO_GRAM, V>), grid, block, smem, s, st);          \
+  } while (0)
+  if (vec) JIRF_SQ_CASE(true); else JIRF_SQ_CASE(false);
+#undef JIRF_SQ_CASE
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
 // batch mean of q for the coupled mode: qmean[c][p] = mean_b q[b][c][p]
 __global__ __launch_bounds__(256) void batch_mean_kernel(const float* __restrict__ q, long q_bs,
                                                          float* __restrict__ out, int B, long n) {
@@ -291,11 +558,13 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
 
   for (int j = tid; j < C; j += 256) {
     float s = 0.f;
+#pragma unroll 8
     for (int sp = 0; sp < splits; ++sp) s += qk_part[(((long)b * splits + sp) * C + i) * C + j];
     s_qk[((long)b * C + i) * C + j] = s;
   }
   if (tid == 0) {
     float q2 = 0.f, k2 = 0.f;
+#pragma unroll 8
     for (int sp = 0; sp < splits; ++sp) {
       q2 += q2_part[((long)b * splits + sp) * C + i];
       k2 += k2_part[((long)b * splits + sp) * C + i];
@@ -308,6 +577,7 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
   const double L = (double)P;
   for (int j = tid; j < C; j += 256) {
     double qs = 0.0, gjj = 0.0;
+#pragma unroll 8
     for (int sp = 0; sp < splits; ++sp) {
       qs += qsum_part[((long)g * splits + sp) * C + j];
       gjj += gram_part[(((long)g * splits + sp) * C + j) * C + j];
@@ -321,6 +591,7 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
   const double mi = mean[i], di = dstd[i];
   for (int j = tid; j < C; j += 256) {
     double gij = 0.0;
+#pragma unroll 8
     for (int sp = 0; sp < splits; ++sp) gij += gram_part[(((long)g * splits + sp) * C + i) * C + j];
     acc += ((gij - L * mi * mean[j]) / (L - 1.0)) / (di * dstd[j]);
   }
@@ -639,6 +910,13 @@ __global__ __launch_bounds__(256) void cache_update_kernel(const CacheUpdArgs a)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// enough workgroups to fill the chip, but at least 8 chunks (256 px) per split
+static int stats_splits(int tiles, int B, int P) {
+  const int chunks = (P + ST_CH - 1) / ST_CH;
+  const int want = (1024 + tiles * tiles * B - 1) / (tiles * tiles * B);
+  return std::min(32, std::max(1, std::min(want, chunks / 8)));
+}
+
 HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode) {
   HintAttnShape sh{};
   sh.B = B; sh.C = C; sh.P = P;
@@ -651,13 +929,7 @@ HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode) {
     sh.goff[i] = off;
     off += sh.gsz[i];
   }
-  const int tiles = (C + ST_T - 1) / ST_T;
-  const int chunks = (P + ST_CH - 1) / ST_CH;
-  // enough workgroups to fill the chip, but at least 8 chunks (256 px) per split
-  int want = (1024 + tiles * tiles * B - 1) / (tiles * tiles * B);
-  int splits = std::max(1, std::min(want, chunks / 8));
-  splits = std::min(splits, 64);
-  sh.splits = splits;
+  sh.splits = stats_splits((C + SQ_T - 1) / SQ_T, B, P);
   return sh;
 }
 
@@ -705,7 +977,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
   JIRF_REQUIRE(sh.gsz[0] > 0 && sh.goff[3] + sh.gsz[3] <= C, JIRF_EINVAL,
                "hint attention: channel count %d too small for 4 groups", C);
   JIRF_REQUIRE(P >= 2, JIRF_EINVAL, "hint attention: needs at least 2 pixels");
-  const int tiles = (C + ST_T - 1) / ST_T;
+  const int tiles = (C + SQ_T - 1) / SQ_T;
   const int chunks = (P + ST_CH - 1) / ST_CH;
   const int cps = (chunks + sh.splits - 1) / sh.splits;
   float* q2_part = sc.q2_part;
@@ -717,11 +989,11 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
   st.C = C; st.P = P; st.tiles = tiles; st.splits = sh.splits; st.chunks_per_split = cps;
   st.qk_part = sc.qk_part; st.gram_part = sc.gram_part; st.qsum_part = sc.qsum_part;
   st.q2_part = q2_part; st.k2_part = k2_part;
-  const double tile_px = (double)tiles * tiles * ST_T * ST_T * (double)P;
+  const double tile_px = (double)C * C * (double)P;
   if (ipg == 1) {
     st.qg = q.p; st.qg_bs = q.bs;
     Scope scope(intern_label("hint_chan_stats C%d P%d S%d", C, P, sh.splits), 4.0 * tile_px * B, 8.0 * B * (double)C * P, s);
-    launch_chan_stats<true, true>(st, B, s);
+    launch_chan_stats96<true, true>(st, B, s);
   } else {
     {
       Scope scope("hint_batch_mean", (double)B * C * P, 4.0 * (B + 1) * (double)C * P, s);
@@ -731,11 +1003,11 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     }
     {
       Scope scope("hint_chan_stats", 2.0 * tile_px * B, 8.0 * B * (double)C * P, s);
-      launch_chan_stats<true, false>(st, B, s);
+      launch_chan_stats96<true, false>(st, B, s);
     }
     st.qg = sc.qmean; st.qg_bs = 0;
     Scope scope("hint_chan_stats", 2.0 * tile_px, 4.0 * (double)C * P, s);
-    launch_chan_stats<false, true>(st, 1, s);
+    launch_chan_stats96<false, true>(st, 1, s);
   }
   JIRF_HIP_CHECK(hipGetLastError());
   {
@@ -916,7 +1188,7 @@ size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, Head
   return off;
 }
 
-int head_attn_splits(int B, int C, int P) { return hint_attn_shape(B, C, P, JIRF_BATCH_PER_IMAGE).splits; }
+int head_attn_splits(int B, int C, int P) { return stats_splits((C + ST_T - 1) / ST_T, B, P); }
 
 void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const float* temperature,
                            const float* ca_w, const float* ca_b, const HeadAttnScratch& sc,
