@@ -545,11 +545,69 @@ __device__ __forceinline__ double block_sum_double(double v, double* red) {
   return r;
 }
 
+// Sums the split-K slabs of every matrix / vector element into slab 0.  32 elements per
+// workgroup, 8 threads per element: thread `part` adds slabs part, part + 8, ... in order, the
+// eight partial sums are then added in order, so the result does not depend on scheduling.
+template <typename T>
+__device__ __forceinline__ void reduce_slabs_part(T* __restrict__ base, long stride, int splits,
+                                                  int part, T* __restrict__ red, int el, bool on) {
+  T t = 0;
+  if (on) {
+#pragma unroll 8
+    for (int sp = part; sp < splits; sp += 8) t += base[(long)sp * stride];
+  }
+  red[part * 32 + el] = t;
+  __syncthreads();
+  if (on && part == 0) {
+    T u = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u += red[q * 32 + el];
+    base[0] = u;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ qk_part,
+                                                           double* __restrict__ gram_part,
+                                                           double* __restrict__ qsum_part,
+                                                           float* __restrict__ q2_part,
+                                                           float* __restrict__ k2_part, int C,
+                                                           int splits, int B, int G) {
+  __shared__ double red_d[256];
+  __shared__ float red_f[256];
+  const int el = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const long e = (long)blockIdx.x * 32 + el;
+  const int b = blockIdx.y;
+  const long CC = (long)C * C;
+  // matrices: elements [0, CC); vectors: elements [CC, CC + C)  (block-uniform split: CC % 32 == 0
+  // is not assumed, so both branches are evaluated per thread with `on` masks)
+  const bool mat = e < CC, vec = e >= CC && e < CC + C;
+  const long c = e - CC;
+  reduce_slabs_part<float>(qk_part + (long)b * splits * CC + (mat ? e : 0), CC, splits, part, red_f, el, mat && b < B);
+  if (gram_part)
+    reduce_slabs_part<double>(gram_part + (long)(b < G ? b : 0) * splits * CC + (mat ? e : 0), CC, splits, part, red_d, el,
+                              mat && b < G);
+  reduce_slabs_part<float>(q2_part + (long)b * splits * C + (vec ? c : 0), C, splits, part, red_f, el, vec && b < B);
+  reduce_slabs_part<float>(k2_part + (long)b * splits * C + (vec ? c : 0), C, splits, part, red_f, el, vec && b < B);
+  if (qsum_part)
+    reduce_slabs_part<double>(qsum_part + (long)(b < G ? b : 0) * splits * C + (vec ? c : 0), C, splits, part, red_d, el,
+                              vec && b < G);
+}
+
+static void launch_reduce_slabs(float* qk_part, double* gram_part, double* qsum_part, float* q2_part,
+                                float* k2_part, int C, int splits, int B, int G, hipStream_t s) {
+  if (splits <= 1) return;
+  const long n = (long)C * C + C;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 31) / 32), std::max(B, G)), dim3(256), 0, s,
+                     qk_part, gram_part, qsum_part, q2_part, k2_part, C, splits, B, G);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void regroup_rows_kernel(
     const float* __restrict__ qk_part, const double* __restrict__ gram_part,
     const double* __restrict__ qsum_part, const float* __restrict__ q2_part,
     const float* __restrict__ k2_part, float* __restrict__ s_qk, float* __restrict__ rq,
-    float* __restrict__ rk, double* __restrict__ sim, int C, int P, int splits, int ipg) {
+    float* __restrict__ rk, double* __restrict__ sim, int C, int P, int splits, int nsum, int ipg) {
   extern __shared__ double dsm[];  // mean[C], dstd[C], red[256]
   double* mean = dsm;
   double* dstd = dsm + C;
@@ -559,13 +617,13 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
   for (int j = tid; j < C; j += 256) {
     float s = 0.f;
 #pragma unroll 8
-    for (int sp = 0; sp < splits; ++sp) s += qk_part[(((long)b * splits + sp) * C + i) * C + j];
+    for (int sp = 0; sp < nsum; ++sp) s += qk_part[(((long)b * splits + sp) * C + i) * C + j];
     s_qk[((long)b * C + i) * C + j] = s;
   }
   if (tid == 0) {
     float q2 = 0.f, k2 = 0.f;
 #pragma unroll 8
-    for (int sp = 0; sp < splits; ++sp) {
+    for (int sp = 0; sp < nsum; ++sp) {
       q2 += q2_part[((long)b * splits + sp) * C + i];
       k2 += k2_part[((long)b * splits + sp) * C + i];
     }
@@ -578,7 +636,7 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
   for (int j = tid; j < C; j += 256) {
     double qs = 0.0, gjj = 0.0;
 #pragma unroll 8
-    for (int sp = 0; sp < splits; ++sp) {
+    for (int sp = 0; sp < nsum; ++sp) {
       qs += qsum_part[((long)g * splits + sp) * C + j];
       gjj += gram_part[(((long)g * splits + sp) * C + j) * C + j];
     }
@@ -592,7 +650,7 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
   for (int j = tid; j < C; j += 256) {
     double gij = 0.0;
 #pragma unroll 8
-    for (int sp = 0; sp < splits; ++sp) gij += gram_part[(((long)g * splits + sp) * C + i) * C + j];
+    for (int sp = 0; sp < nsum; ++sp) gij += gram_part[(((long)g * splits + sp) * C + i) * C + j];
     acc += ((gij - L * mi * mean[j]) / (L - 1.0)) / (di * dstd[j]);
   }
   const double tot = block_sum_double(acc, red);
@@ -914,7 +972,10 @@ __global__ __launch_bounds__(256) void cache_update_kernel(const CacheUpdArgs a)
 static int stats_splits(int tiles, int B, int P) {
   const int chunks = (P + ST_CH - 1) / ST_CH;
   const int want = (1024 + tiles * tiles * B - 1) / (tiles * tiles * B);
-  return std::min(32, std::max(1, std::min(want, chunks / 8)));
+  // more slabs cost the reduction kernel time in proportion to splits * B: allow many only while
+  // the batch is small
+  const int cap = std::min(256, std::max(32, 512 / (tiles * tiles * B)));
+  return std::min(cap, std::max(1, std::min(want, chunks / 8)));
 }
 
 HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode) {
@@ -1014,8 +1075,9 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     Scope scope("hint_regroup_rows", 3.0 * C * (double)C * sh.splits * B,
                 (double)C * C * sh.splits * (4.0 * B + 8.0 * G), s);
     const size_t smem = (2 * (size_t)C + 256) * sizeof(double);
+    launch_reduce_slabs(sc.qk_part, sc.gram_part, sc.qsum_part, q2_part, k2_part, C, sh.splits, B, G, s);
     hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), smem, s, sc.qk_part, sc.gram_part,
-                       sc.qsum_part, q2_part, k2_part, sc.s_qk, sc.rq, sc.rk, sim, C, P, sh.splits,
+                       sc.qsum_part, q2_part, k2_part, sc.s_qk, sc.rq, sc.rk, sim, C, P, sh.splits, 1,
                        ipg);
     JIRF_HIP_CHECK(hipGetLastError());
   }
@@ -1213,8 +1275,9 @@ void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const flo
   }
   {
     Scope scope("head_reduce_rows", 1.0 * C * (double)C * splits * B, 4.0 * C * (double)C * splits * B, s);
+    launch_reduce_slabs(sc.qk_part, nullptr, nullptr, sc.q2_part, sc.k2_part, C, splits, B, 0, s);
     hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), 0, s, sc.qk_part, nullptr, nullptr,
-                       sc.q2_part, sc.k2_part, sc.s_qk, sc.rq, sc.rk, nullptr, C, P, splits, 1);
+                       sc.q2_part, sc.k2_part, sc.s_qk, sc.rq, sc.rk, nullptr, C, P, splits, 1, 1);
     JIRF_HIP_CHECK(hipGetLastError());
   }
   {
