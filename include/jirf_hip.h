@@ -56,10 +56,11 @@ const char* jirf_last_error(void);
 /* ---- network objects ------------------------------------------------------------------- */
 
 /* Stands in for `cls(**opt)` of define_network (archs/__init__.py:22-47) with
- * arch in {"HINT"} (ctor kwargs of hint_arch.py:495-508) — "ASTv2"
- * (astv2_arch.py:303-315) and "AST" (ast_arch.py:941-965) are accepted once
- * their kernels are built.  cfg_json is the `network_g` YAML block without
- * `type`, as JSON.  Unknown arch: NULL + JIRF_ENOTFOUND. */
+ * arch in {"HINT" (ctor kwargs of hint_arch.py:495-508), "ASTv2"
+ * (astv2_arch.py:303-315), "AST" (ast_arch.py:941-965; token_mlp "frfn", the
+ * only feed-forward its configs use)}.  cfg_json is the `network_g` YAML block
+ * without `type`, as JSON.  Unknown arch: NULL + JIRF_ENOTFOUND; unknown
+ * option: NULL + JIRF_EINVAL. */
 jirf_net* jirf_net_create(const char* arch, const char* cfg_json, int device);
 void jirf_net_destroy(jirf_net* net);
 
@@ -152,7 +153,8 @@ int jirf_op_layernorm(const float* x, const float* w, const float* b, float* y, 
                       int kind, void* stream);
 /* HINT channel attention core (Attention.execute hint_arch.py:351-399 without the two convs and
  * without the intra-modulator): qkv [B,3C,P] device; writes out [B,C,P] (sorted channel order),
- * tcache [B,C,P] (= normalised q + k in sorted order), perm [G,C] int32, att [B,C,C]
+ * tcache [B,C,P] (= out + normalised q + normalised k in sorted order, the intra-modulator's
+ * input x2 + x1 of hint_arch.py:226,401), perm [G,C] int32, att [B,C,C]
  * (block-diagonal attention after inter-modulation), cache_out [G,C,C].  cache_in NULL = None,
  * else [G,Cc,Cc].  G = B (per-image) or 1 (coupled).  params_host: the reference tensors
  * temperature[4], then for g in 0..3 conv_width.weight[2c,c], conv_width.bias[2c],

@@ -2,7 +2,8 @@
 # Collects the profiles kept in this directory.  Run on the GPU box from the repository root:
 #   bash profiles/collect.sh <tag>        (tag e.g. r01)
 # 1. rocprofv3 --kernel-trace --stats over the default benchmark command (short step count)
-# 2. two PMC passes (reads, writes: they do not fit one pass) over the dominant launch shape alone
+# 2. over the dominant launch shape alone (profiles/pmc_op.py): two PMC passes (reads, writes:
+#    they do not fit one pass) and one kernel-trace pass
 set -e
 tag=${1:-r01}
 out=gpurun_out/prof_$tag
@@ -11,4 +12,5 @@ export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o pmc -- python3 profiles/pmc_op.py
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o pmc -- python3 profiles/pmc_op.py
+timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $out/op_trace -o op -- python3 profiles/pmc_op.py
 find $out -type f | head -50

@@ -62,7 +62,15 @@ for o in out.values():
     rd = 2.0 * 1024.0 * o.get("FETCH_SIZE_KiB_per_launch", 0.0)
     wr = 1024.0 * o.get("WRITE_SIZE_KiB_per_launch", 0.0)
     o.update({"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr})
-res = {"op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
+iso = None
+p_iso = os.path.join(src, "op_trace", "op_results.db")
+if os.path.exists(p_iso):
+    d = sqlite3.connect(p_iso)
+    r = d.execute("select avg(duration), count(*) from kernels where name like '%gemm%'").fetchone()
+    iso = {"avg_ns": r[0], "launches": r[1],
+           "note": "same launch shape run alone on N(0,1) inputs (profiles/pmc_op.py); the clock the chip holds, and "
+                   "with it the duration, depends on the operand data, so this differs from the in-network launches"}
+res = {"isolated_kernel_trace": iso, "op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
        "algorithmic_bytes_per_launch": 4.0 * 16 * 65536 * (96 + 510),
        "kernels": out}
 with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
