@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="256x256 crops per GPU per step")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--height", type=int, default=0, help="image height (default: --size)")
+    ap.add_argument("--width", type=int, default=0, help="image width (default: --size)")
+    ap.add_argument("--arch", default="HINT", choices=["HINT", "ASTv2", "AST"],
+                    help="network; the headline workload is HINT (the other two are parity configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", default=None, help="write the per-shape kernel table to this file")
@@ -104,21 +108,32 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from oracle import hint_oracle as ho
-    from oracle.weights import make_hint_state, synthetic_images
+    from oracle.weights import make_hint_state, make_astv2_state, make_ast_state, synthetic_images
     from basicsr.models.archs import define_network
 
-    cfg = ho.default_config()
-    sd = make_hint_state(cfg, seed=1, gain=0.6)
-    net = define_network(dict(cfg, type="HINT"))
+    if args.arch == "HINT":
+        cfg = ho.default_config()
+        sd = make_hint_state(cfg, seed=1, gain=0.6)
+    elif args.arch == "ASTv2":
+        from oracle import astv2_oracle as oracle_mod
+        cfg = oracle_mod.default_config()
+        sd = make_astv2_state(cfg, seed=1, gain=0.6)
+    else:
+        from oracle import ast_oracle as oracle_mod
+        cfg = oracle_mod.default_config()
+        sd = make_ast_state(cfg, seed=1, gain=0.5)
+    net = define_network(dict(cfg, type=args.arch))
     net.load_state_dict(sd)
     net.cuda(local_rank).eval()
     net.batch_mode = "per_image"
 
     B, S = args.batch, args.size
-    x = torch.from_numpy(synthetic_images(B, S, S, seed=100 + rank, sigma=50)).cuda()
+    Hh, Ww = args.height or S, args.width or S
+    x = torch.from_numpy(synthetic_images(B, Hh, Ww, seed=100 + rank, sigma=50)).cuda()
 
     def step():
-        net.qv_cache = None          # every image is a cold-start call
+        if args.arch == "HINT":
+            net.qv_cache = None      # every image is a cold-start call
         return net(x)
 
     def sync_all():
@@ -141,19 +156,22 @@ def main():
         elapsed = float(t.item())
     assert bool(torch.isfinite(y).all()), "non-finite output"
 
-    mp_per_step = world * B * S * S / 1e6
+    mp_per_step = world * B * Hh * Ww / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     value = mp_per_step / (ms_per_step / 1e3)
-    flops_img = hint_flops_per_image(cfg, S, S)
+    flops_img = hint_flops_per_image(cfg, Hh, Ww) if args.arch == "HINT" else 0.0
     out = {
-        "metric": "restored megapixels/sec (node), HINT sigma=50 denoising forward, 256x256 crops",
+        "metric": "restored megapixels/sec (node), HINT sigma=50 denoising forward, 256x256 crops"
+                  if (args.arch, Hh, Ww) == ("HINT", 256, 256) else
+                  f"restored megapixels/sec (node), {args.arch} forward, {Ww}x{Hh} images",
         "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "ms_per_image": round(ms_per_step / B, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (uniform [0,1) RGB + N(0,(50/255)^2) noise; seeded random weights in the reference key layout)",
-        "config": {"workload": f"HINT (dim 48, blocks [4,6,6,8], refine 4, ffn 2.66) forward on a batch of {B} "
-                               f"{S}x{S} RGB crops per GPU, cold-start per image, fp32",
-                   "batch_per_gpu": B, "height": S, "width": S, "sharding": "images round-robin over ranks, no collective"},
+        "config": {"workload": (f"HINT (dim 48, blocks [4,6,6,8], refine 4, ffn 2.66) forward on a batch of {B} "
+                                f"{Ww}x{Hh} RGB crops per GPU, cold-start per image, fp32") if args.arch == "HINT" else
+                               f"{args.arch} (reference default constructor) forward on a batch of {B} {Ww}x{Hh} RGB images per GPU, fp32",
+                   "batch_per_gpu": B, "height": Hh, "width": Ww, "sharding": "images round-robin over ranks, no collective"},
         "model_tflops_per_s": round(world * B * flops_img / (ms_per_step / 1e3) / 1e12, 2),
         "frac_of_f32_mfma_peak": round(B * flops_img / (ms_per_step / 1e3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
     }
@@ -209,10 +227,15 @@ def main():
         torch.set_num_threads(cores)
         xs = x[:1].cpu()
         t0 = time.perf_counter()
-        ho.hint_forward(sd, xs, cfg, None)
+        if args.arch == "HINT":
+            ho.hint_forward(sd, xs, cfg, None)
+        elif args.arch == "ASTv2":
+            oracle_mod.astv2_forward(sd, xs, cfg)
+        else:
+            oracle_mod.ast_forward(sd, xs, cfg)
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(S * S / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
-                               "sample": f"1 image {S}x{S} through oracle/hint_oracle.py (torch-CPU fp32), {dt:.1f} s"}
+        out["cpu_baseline"] = {"value": round(Hh * Ww / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
+                               "sample": f"1 image {Ww}x{Hh} through the oracle/ restatement of {args.arch} (torch-CPU fp32), {dt:.1f} s"}
 
     if use_dist:
         dist.barrier()

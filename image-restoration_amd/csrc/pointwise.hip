@@ -53,18 +53,103 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// Stand-alone LayerNorm, channels dealt over the 4 waves of a workgroup: a workgroup owns 64 * PX
+// adjacent pixels (PX = 4: one float4 per lane), every wave reduces its channel slice, the partial
+// sums meet in LDS, and each wave writes its own slice.  Passes 2 and 3 re-read lines pass 1 left
+// in L2.  Same two-pass statistics as layernorm_kernel.
+template <int KIND, int PX>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, long x_bs,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ y, long y_bs, int C, int P) {
+  __shared__ float part[2][4][64 * PX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = (blockIdx.x * 64 + lane) * PX;
+  const int b = blockIdx.y;
+  const bool ok = p < P;   // PX == 4 requires P % 4 == 0, so a lane is all in or all out
+  const float* __restrict__ xp = x + (long)b * x_bs + (ok ? p : 0);
+  float* __restrict__ yp = y + (long)b * y_bs + (ok ? p : 0);
+  float v[PX], s[PX];
+  auto load = [&](int c) {
+    if constexpr (PX == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(xp + (long)c * P);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      v[0] = xp[(long)c * P];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < PX; ++i) s[i] = 0.f;
+#pragma unroll 4
+  for (int c = wave; c < C; c += 4) {
+    load(c);
+#pragma unroll
+    for (int i = 0; i < PX; ++i) s[i] += v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < PX; ++i) part[0][wave][lane * PX + i] = s[i];
+  __syncthreads();
+  float mu[PX], rstd[PX];
+#pragma unroll
+  for (int i = 0; i < PX; ++i) {
+    const int q = lane * PX + i;
+    mu[i] = (part[0][0][q] + part[0][1][q] + part[0][2][q] + part[0][3][q]) / (float)C;
+    s[i] = 0.f;
+  }
+#pragma unroll 4
+  for (int c = wave; c < C; c += 4) {
+    load(c);
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      const float d = v[i] - mu[i];
+      s[i] = fmaf(d, d, s[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PX; ++i) part[1][wave][lane * PX + i] = s[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PX; ++i) {
+    const int q = lane * PX + i;
+    rstd[i] = 1.0f / sqrtf((part[1][0][q] + part[1][1][q] + part[1][2][q] + part[1][3][q]) / (float)C + 1e-5f);
+  }
+  if (!ok) return;
+#pragma unroll 4
+  for (int c = wave; c < C; c += 4) {
+    load(c);
+    const float g = w[c];
+    float o[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      if constexpr (KIND == 1) o[i] = (v[i] - mu[i]) * rstd[i] * g + bias[c];
+      else o[i] = v[i] * rstd[i] * g;
+    }
+    if constexpr (PX == 4) *reinterpret_cast<float4*>(yp + (long)c * P) = make_float4(o[0], o[1], o[2], o[3]);
+    else yp[(long)c * P] = o[0];
+  }
+}
+
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s) {
   JIRF_REQUIRE(kind == 1 || kind == 2, JIRF_EINVAL, "layernorm: kind %d", kind);
   JIRF_REQUIRE(kind == 2 || b != nullptr, JIRF_EINVAL, "layernorm: WithBias needs a bias");
-  const dim3 grid((P + 255) / 256, B), block(256);
-  Scope sc("layernorm", 8.0 * B * (double)C * P, 8.0 * B * (double)C * P, s);
-  if (kind == 1)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, nullptr,
-                       nullptr, C, P);
-  else
-    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, nullptr,
-                       nullptr, C, P);
+  Scope sc(intern_label("layernorm C%d P%d", C, P), 8.0 * B * (double)C * P, 8.0 * B * (double)C * P, s);
+  const bool vec = P % 4 == 0 && x.bs % 4 == 0 && y.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(y.p) & 15) == 0 && (long)B * P >= 256L * 1024;
+  const dim3 block(256);
+  if (vec) {
+    const dim3 grid((P + 255) / 256, B);
+    if (kind == 1)
+      hipLaunchKernelGGL((layernorm_split_kernel<1, 4>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P);
+    else
+      hipLaunchKernelGGL((layernorm_split_kernel<2, 4>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P);
+  } else {
+    const dim3 grid((P + 63) / 64, B);
+    if (kind == 1)
+      hipLaunchKernelGGL((layernorm_split_kernel<1, 1>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P);
+    else
+      hipLaunchKernelGGL((layernorm_split_kernel<2, 1>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P);
+  }
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
