@@ -120,3 +120,66 @@ def test_batch_coupling_is_visible():
     assert float((y_c - y_p).abs().max()) > 1e-4
     y0, _ = ho.hint_forward(sd, x[:1], TINY)
     assert torch.equal(y0, y_p[:1])
+
+
+# ---- ASTv2 / AST oracles ---------------------------------------------------------------------------
+def test_astv2_and_ast_oracles_reproduce_golden():
+    from oracle import ast_oracle, astv2_oracle
+    from oracle.weights import make_ast_state, make_astv2_state
+    from tests.make_golden import AST_SHALLOW, ASTV2_SMALL
+    g = np.load(os.path.join(GOLD, "astv2_small_40x56.npz"))
+    sd = make_astv2_state(ASTV2_SMALL, seed=int(g["seed"]), gain=0.6)
+    assert weights_digest(sd) == str(g["weights_sha256"])
+    y = astv2_oracle.astv2_forward(sd, torch.from_numpy(g["x"]), ASTV2_SMALL).numpy()
+    assert np.abs(y - g["y"]).max() < 2e-5
+    g = np.load(os.path.join(GOLD, "ast_shallow_128.npz"))
+    sd = make_ast_state(AST_SHALLOW, seed=int(g["seed"]), gain=0.5)
+    assert weights_digest(sd) == str(g["weights_sha256"])
+    y = ast_oracle.ast_forward(sd, torch.from_numpy(g["x"]), AST_SHALLOW).numpy()
+    assert np.abs(y - g["y"]).max() < 2e-5
+
+
+def test_ast_relative_position_index_and_shift_mask():
+    from oracle import ast_oracle as so
+    idx = so.relative_position_index(8).numpy()
+    for p in range(64):           # literal loop form of ast_arch.py:248-257
+        for q in range(64):
+            assert idx[p, q] == (p // 8 - q // 8 + 7) * 15 + (p % 8 - q % 8 + 7)
+    assert idx.min() == 0 and idx.max() == 224
+    H = W = 16
+    m = so.shift_attn_mask(H, W, 8, 4).numpy()        # [nW, 64, 64]
+    region = np.zeros((H, W), np.int64)
+    for y in range(H):
+        for x in range(W):
+            ry = 0 if y < H - 8 else (1 if y < H - 4 else 2)
+            rx = 0 if x < W - 8 else (1 if x < W - 4 else 2)
+            region[y, x] = 3 * ry + rx
+    for w in range(4):
+        wy, wx = divmod(w, 2)
+        r = region[wy * 8:wy * 8 + 8, wx * 8:wx * 8 + 8].reshape(-1)
+        want = np.where(r[None, :] != r[:, None], -100.0, 0.0)
+        assert np.array_equal(m[w], want)
+
+
+def test_ast_bmm_4d_pairs_q_with_another_windows_k():
+    """The flattening of ast_arch.py:33-49: q is laid out [window, head], k [head, window], so score
+    block j = b * heads + h multiplies q[b, h] with k[j // B_, j % B_]."""
+    from oracle import ast_oracle as so
+    rng = torch.Generator().manual_seed(0)
+    B_, heads, N, D = 6, 2, 4, 3
+    q = torch.randn(B_, heads, N, D, generator=rng)
+    k = torch.randn(heads, B_, N, D, generator=rng)       # the reference's k after its permute
+    got = so.bmm_4d(q, k)
+    for b in range(B_):
+        for h in range(heads):
+            j = b * heads + h
+            assert torch.allclose(got[b, h], q[b, h] @ k[j // B_, j % B_].T, atol=1e-6)
+
+
+def test_ast_window_partition_round_trip():
+    from oracle import ast_oracle as so
+    x = torch.arange(2 * 16 * 24 * 3, dtype=torch.float32).reshape(2, 16, 24, 3)
+    w = so.window_partition(x, 8)
+    assert w.shape == (2 * 2 * 3, 8, 8, 3)
+    assert torch.equal(w[4], x[0, 8:16, 8:16])            # window (1, 1) of image 0
+    assert torch.equal(so.window_reverse(w, 8, 16, 24), x)
