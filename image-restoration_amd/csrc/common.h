@@ -118,6 +118,10 @@ int pack_wt_conv(const float* w, int M, int Cin, int ks, std::vector<float>& out
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s);
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s);
+// Dense 3x3 (stride 1, zero pad 1) with at most 4 output channels, on the vector ALUs; weights in
+// the GEMM's K-major packing wt[(tap * Cin + c) * Mpad + o].  Returns false (nothing launched)
+// when the shape is not one it is built for.
+bool try_launch_conv3x3_fewout(const struct GemmArgs& a, hipStream_t s);
 // gate: 0 plain, 1 gelu(dw(x1)) * dw(x2), 2 dw(x1) * x2, 3 gelu(dw(x1)) * x2.  wmod/wconv: ASTv2 partial convolution
 // (channel c uses weight c % wmod when c % wmod < wconv, and is copied through otherwise).
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,

@@ -665,6 +665,9 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   if (a.epi == EP_AV_INTRA) bytes += 4.0 * a.B * (double)a.P * a.M * 3;
   Scope sc(intern_label("%s M%d K%d P%d", name, a.M, a.K, a.P), flops, bytes, s);
 
+  // the RGB output convolutions: a handful of output rows would idle the matrix cores
+  if (loader == LD_CONV3 && !std::getenv("JIRF_GEMM_TILE") && try_launch_conv3x3_fewout(a, s)) return;
+
   // Kernel choice, from per-shape measurements on MI355X (HINT / ASTv2 / AST shapes, B = 16):
   //  * activation-stationary kernel when LayerNorm rides on the load (it also replaces the
   //    statistics pass), for attention * V with K <= 128, and for plain loads with a short K and

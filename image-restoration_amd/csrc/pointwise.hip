@@ -467,4 +467,115 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
+// ---- dense 3x3 with a handful of output channels (the RGB output convolutions) ------------------
+// As a GEMM this shape wastes 61 of 64 tile rows.  Here a lane owns 4 adjacent pixels and R rows and
+// keeps COUT x R x 4 accumulators; per input channel it loads R + 2 row segments (float4 + the two
+// neighbours from the adjacent lanes) and the 9 x COUT weights arrive as scalar loads.
+template <int COUT, int R>
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ wt, int Mpad,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ res, long r_bs,
+                                                             float* __restrict__ y, long y_bs, int Cin,
+                                                             int H, int W, int lx_log2, int tiles_x,
+                                                             int n_tasks) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= n_tasks) return;  // whole wave
+  const int b = blockIdx.y;
+  const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
+  const int tx = task % tiles_x, ts = task / tiles_x;
+  const int xq = lane & (LX - 1), yr = lane >> lx_log2;
+  const int px = (tx * LX + xq) * 4;
+  const int ys = (ts * RW + yr) * R;
+  const long P = (long)H * W;
+  const bool x_ok = px < W;
+  float acc[COUT][R][4];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[o][i][j] = 0.f;
+  const float* __restrict__ xb = x + (long)b * x_bs;
+  for (int c = 0; c < Cin; ++c) {
+    const float* __restrict__ plane = xb + (long)c * P;
+    float wv[9][COUT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) wv[t][o] = wt[(long)(t * Cin + c) * Mpad + o];
+    float row[R + 2][6];
+#pragma unroll
+    for (int i = 0; i < R + 2; ++i) {
+      const int yy = ys + i - 1;
+      const bool ok = x_ok && yy >= 0 && yy < H;
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* __restrict__ p = plane + (long)yy * W + px;
+      if (ok) m = *reinterpret_cast<const float4*>(p);
+      float l = __shfl_up(m.w, 1), rr = __shfl_down(m.x, 1);
+      if (xq == 0) l = (ok && px > 0) ? p[-1] : 0.f;
+      if (xq == LX - 1 || px + 4 >= W) rr = (ok && px + 4 < W) ? p[4] : 0.f;
+      row[i][0] = l; row[i][1] = m.x; row[i][2] = m.y; row[i][3] = m.z; row[i][4] = m.w; row[i][5] = rr;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < COUT; ++o)
+              acc[o][i][j] = fmaf(wv[ky * 3 + kx][o], row[i + ky][j + kx], acc[o][i][j]);
+  }
+  if (!x_ok) return;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    const float bo = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int oy = ys + i;
+      if (oy >= H) continue;
+      const long off = (long)o * P + (long)oy * W + px;
+      float4 v = make_float4(acc[o][i][0] + bo, acc[o][i][1] + bo, acc[o][i][2] + bo, acc[o][i][3] + bo);
+      if (res) {
+        const float4 rv = *reinterpret_cast<const float4*>(res + (long)b * r_bs + off);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      *reinterpret_cast<float4*>(y + (long)b * y_bs + off) = v;
+    }
+  }
+}
+
+bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
+  auto al = [](const float* p, long bs) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && bs % 4 == 0; };
+  const bool shape_ok = a.M >= 1 && a.M <= 4 && a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Hin == a.H &&
+                        a.Win == a.W && a.W % 4 == 0 && (a.epi == EP_STORE || a.epi == EP_RESID) && a.wt_bs == 0 &&
+                        al(a.x.p, a.x.bs) && al(a.y.p, a.y.bs) && (a.epi != EP_RESID || al(a.r.p, a.r.bs));
+  if (!shape_ok) return false;
+  const int H = a.H, W = a.W;
+  constexpr int R = 4;
+  int lx_log2 = 0;
+  while ((1 << lx_log2) < 64 && (4 << lx_log2) < W) ++lx_log2;
+  const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
+  const int tiles_x = (W + 4 * LX - 1) / (4 * LX), strips = (H + RW * R - 1) / (RW * R);
+  const int n_tasks = tiles_x * strips;
+  const dim3 grid((unsigned)((n_tasks + 3) / 4), a.B), block(256);
+  const float* res = a.epi == EP_RESID ? a.r.p : nullptr;
+#define JIRF_FEWOUT(CO)                                                                              \
+  hipLaunchKernelGGL((conv3x3_fewout_kernel<CO, R>), grid, block, 0, s, a.x.p, a.x.bs, a.wt, a.Mpad, a.bias, res, \
+                     a.r.bs, a.y.p, a.y.bs, a.Cin, H, W, lx_log2, tiles_x, n_tasks)
+  switch (a.M) {
+    case 1: JIRF_FEWOUT(1); break;
+    case 2: JIRF_FEWOUT(2); break;
+    case 3: JIRF_FEWOUT(3); break;
+    default: JIRF_FEWOUT(4); break;
+  }
+#undef JIRF_FEWOUT
+  JIRF_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 }  // namespace jirf
