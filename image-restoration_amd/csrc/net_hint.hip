@@ -32,7 +32,7 @@ struct HintBlock {
   int C = 0, hidden = 0;
   bool att = false;
   LNW n1, n2;
-  PackedW qkv, proj, gate, down, up, pin, pout;
+  PackedW qkv, gate, tail, pin, pout;   // tail: project_out folded with the intra-modulator's down/up
   DWW qkv_dw, ffn_dw;
   HintAttnWeights aw{};
 };
@@ -103,6 +103,43 @@ class HintNet final : public Net {
       return pack_upload_3x3(pool_, host(k + ".weight").data(), b ? host(k + ".bias").data() : nullptr, M, Cin);
     };
     auto vec = [&](const std::string& k) { return pool_.upload(host(k)); };
+    // Everything after the gate of the intra-modulator is linear (hint_arch.py:226-228,401,
+    // :403 project_out):  y = x + Wp (Wu (Wd g + bd) + bu + out) + bp  with g the gated tensor and
+    // out = attention * V.  Folded in double precision into ONE 1x1 conv over the stacked input
+    // [g; out]:  W = [Wp Wu Wd | Wp],  b = Wp (Wu bd + bu) + bp  -- three HBM-bound pointwise
+    // GEMMs and two intermediate tensors fewer per block.
+    auto fold_attention_tail = [&](const std::string& a, int C) {
+      const int Ch = C / 2;
+      const std::vector<float>& Wp = host(a + ".project_out.weight");              // [C][C]
+      const std::vector<float>& Wd = host(a + ".intra_modulator.down.weight");      // [Ch][C]
+      const std::vector<float>& bd = host(a + ".intra_modulator.down.bias");
+      const std::vector<float>& Wu = host(a + ".intra_modulator.up.weight");        // [C][Ch]
+      const std::vector<float>& bu = host(a + ".intra_modulator.up.bias");
+      std::vector<double> ud((size_t)C * C), bud(C);
+      for (int i = 0; i < C; ++i) {
+        for (int j = 0; j < C; ++j) {
+          double t = 0.0;
+          for (int m = 0; m < Ch; ++m) t += (double)Wu[(size_t)i * Ch + m] * (double)Wd[(size_t)m * C + j];
+          ud[(size_t)i * C + j] = t;
+        }
+        double t = bu[i];
+        for (int m = 0; m < Ch; ++m) t += (double)Wu[(size_t)i * Ch + m] * (double)bd[m];
+        bud[i] = t;
+      }
+      std::vector<float> W((size_t)C * 2 * C), b(C);
+      for (int i = 0; i < C; ++i) {
+        for (int j = 0; j < C; ++j) {
+          double t = 0.0;
+          for (int m = 0; m < C; ++m) t += (double)Wp[(size_t)i * C + m] * ud[(size_t)m * C + j];
+          W[(size_t)i * 2 * C + j] = (float)t;
+          W[(size_t)i * 2 * C + C + j] = Wp[(size_t)i * C + j];
+        }
+        double t = bias_ ? (double)host(a + ".project_out.bias")[i] : 0.0;
+        for (int m = 0; m < C; ++m) t += (double)Wp[(size_t)i * C + m] * bud[m];
+        b[i] = (float)t;
+      }
+      return pack_upload_1x1(pool_, W.data(), b.data(), C, 2 * C);
+    };
     for (auto& st : stages_) {
       for (auto& bl : st.blocks) {
         const std::string& n = bl.name;
@@ -114,10 +151,8 @@ class HintNet final : public Net {
           bl.qkv = conv1(a + ".qkv", 3 * C, C);
           bl.qkv_dw.w = vec(a + ".qkv_dwconv.weight");
           if (bias_) bl.qkv_dw.b = vec(a + ".qkv_dwconv.bias");
-          bl.proj = conv1(a + ".project_out", C, C);
           bl.gate = conv1b(a + ".intra_modulator.gating_conv", C, C);
-          bl.down = conv1b(a + ".intra_modulator.down", C / 2, C);
-          bl.up = conv1b(a + ".intra_modulator.up", C, C / 2);
+          bl.tail = fold_attention_tail(a, C);
           bl.aw.temperature = vec(a + ".temperature");
           for (int g = 0; g < 4; ++g) {
             const std::string m = a + ".inter_modulator" + std::to_string(g + 1);
@@ -439,16 +474,15 @@ class HintNet final : public Net {
       g.wt_bs = (long)((C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD) * g.Mpad;
       g.x = tv_chan(t2, 2 * C, P);
       g.kidx = perm; g.imgs_per_group = B / sh.G;
-      g.y = tv_chan(t1, 0, P); g.y2 = tv_chan(t1, C, P);
+      g.y = tv_chan(t1, C, P); g.y2 = tv_chan(t1, 2 * C, P);
       g.epi = EP_AV_INTRA;
       g.q = tv_chan(t2, 0, P); g.k = tv_chan(t2, C, P);
       g.rq = sc.rq; g.rk = sc.rk;
       launch_gemm(g, LD_GATHER, s);
-      // intra-cache modulation: out + up(down(gelu(Wg s + bg) * s))
-      gemm(bl.gate, tv_chan(t1, C, P), tv_chan(t1, 2 * C, P), B, P, EP_GELU_MUL, tv_chan(t1, C, P), s);
-      gemm(bl.down, tv_chan(t1, 2 * C, P), tv_chan(t2, 0, P), B, P, EP_STORE, TV{}, s);
-      gemm(bl.up, tv_chan(t2, 0, P), tv_chan(t1, C, P), B, P, EP_RESID, tv_chan(t1, 0, P), s);
-      gemm(bl.proj, tv_chan(t1, C, P), x, B, P, EP_RESID, x, s);
+      // intra-cache modulation and project_out: g = gelu(Wg s + bg) * s, then the folded linear tail
+      // over [g; out] (rows 0..C-1 and C..2C-1 of t1) with the block's residual
+      gemm(bl.gate, tv_chan(t1, 2 * C, P), tv_chan(t1, 0, P), B, P, EP_GELU_MUL, tv_chan(t1, 2 * C, P), s);
+      gemm(bl.tail, tv_chan(t1, 0, P), x, B, P, EP_RESID, x, s);
     }
     if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
     gemm(bl.pin, x, t1, B, P, EP_STORE, TV{}, s, LD_LN, &bl.n2);
