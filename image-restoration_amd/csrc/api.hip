@@ -332,6 +332,64 @@ int jirf_op_layernorm(const float* x, const float* w, const float* b, float* y, 
   });
 }
 
+// ---- script-level plumbing -------------------------------------------------------------------------
+namespace {
+TileGrid make_grid(int crop, const int32_t* hstarts, int nh, const int32_t* wstarts, int nw) {
+  JIRF_REQUIRE(hstarts && wstarts && nh >= 1 && nw >= 1 && nh <= TILE_GRID_MAX && nw <= TILE_GRID_MAX, JIRF_EINVAL,
+               "tile grid: %d x %d starts (at most %d per axis)", nh, nw, TILE_GRID_MAX);
+  TileGrid g{};
+  g.crop = crop; g.nh = nh; g.nw = nw;
+  for (int i = 0; i < nh; ++i) g.hs[i] = hstarts[i];
+  for (int i = 0; i < nw; ++i) g.ws[i] = wstarts[i];
+  return g;
+}
+}  // namespace
+
+int jirf_op_reflect_pad(const float* x, float* y, int B, int C, int H, int W, int pad_bottom, int pad_right,
+                        void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "reflect_pad: bad arguments");
+    launch_reflect_pad(x, y, B, C, H, W, pad_bottom, pad_right, static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_split_tiles(const float* x, float* tiles, int B, int C, int H, int W, int crop, const int32_t* hstarts,
+                        int nh, const int32_t* wstarts, int nw, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && tiles && B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "split_tiles: bad arguments");
+    launch_split_tiles(x, tiles, make_grid(crop, hstarts, nh, wstarts, nw), B, C, H, W,
+                       static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_merge_tiles(const float* tiles, float* out, int B, int C, int H, int W, int crop, const int32_t* hstarts,
+                        int nh, const int32_t* wstarts, int nw, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(tiles && out && B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "merge_tiles: bad arguments");
+    launch_merge_tiles(tiles, out, make_grid(crop, hstarts, nh, wstarts, nw), B, C, H, W,
+                       static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_crop_clamp(const float* x, float* y, int B, int C, int H, int W, int h, int w, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && y && B > 0 && C > 0, JIRF_EINVAL, "crop_clamp: bad arguments");
+    launch_crop_clamp(x, y, B, C, H, W, h, w, false, static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_crop_clamp_u8(const float* x, uint8_t* y, int B, int C, int H, int W, int h, int w, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && y && B > 0 && C > 0, JIRF_EINVAL, "crop_clamp_u8: bad arguments");
+    launch_crop_clamp(x, y, B, C, H, W, h, w, true, static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
 int jirf_op_hint_attention_core(const float* qkv, const float* params_host, const float* cache_in,
                                 int cache_c, float* out, float* tcache, int32_t* perm, float* att,
                                 float* cache_out, int B, int C, int P, int batch_mode,

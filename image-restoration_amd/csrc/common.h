@@ -118,6 +118,18 @@ int pack_wt_conv(const float* w, int M, int Cin, int ks, std::vector<float>& out
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s);
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s);
+// ---- script-level image plumbing (harness.hip) ---------------------------------------------------
+constexpr int TILE_GRID_MAX = 96;
+struct TileGrid {            // tiles = row starts x column starts, all of one square size
+  int crop, nh, nw;
+  int hs[TILE_GRID_MAX], ws[TILE_GRID_MAX];
+};
+void launch_reflect_pad(const float* x, float* y, int B, int C, int H, int W, int pad_bottom, int pad_right,
+                        hipStream_t s);
+void launch_split_tiles(const float* x, float* tiles, const TileGrid& g, int B, int C, int H, int W, hipStream_t s);
+void launch_merge_tiles(const float* tiles, float* out, const TileGrid& g, int B, int C, int H, int W, hipStream_t s);
+void launch_crop_clamp(const float* x, void* y, int B, int C, int H, int W, int h, int w, bool to_u8, hipStream_t s);
+
 // Dense 3x3 (stride 1, zero pad 1) with at most 4 output channels, on the vector ALUs; weights in
 // the GEMM's K-major packing wt[(tap * Cin + c) * Mpad + o].  Returns false (nothing launched)
 // when the shape is not one it is built for.

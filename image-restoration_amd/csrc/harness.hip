@@ -1,0 +1,164 @@
+// Script-level image plumbing of the reference's test scripts as gfx950 kernels, so a whole
+// "load -> pad -> (tile) -> restore -> (merge) -> crop -> clamp -> uint8" pass stays on the device:
+//   reflect pad to a multiple of 8      Deraining/test_rain100L.py:147-152
+//   splitimage / mergeimage             Deraining/test_rain100L.py:31-75 (uniform score map: mean blend)
+//   crop + clamp + img_as_ubyte         Deraining/test_rain100L.py:171-190
+// All of it is index or byte work: results are bit-exact against the CPU restatement.
+#include "common.h"
+
+namespace jirf {
+
+// y[b,c,yy,xx] = x[b,c,ry,rx] with reflection (no edge repeat) past the bottom / right border
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int H, int W, int Ho, int Wo, long planes) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = planes * Ho * Wo;
+  if (i >= n) return;
+  const int xx = (int)(i % Wo);
+  const long t = i / Wo;
+  const int yy = (int)(t % Ho);
+  const long pl = t / Ho;
+  const int ry = yy < H ? yy : 2 * (H - 1) - yy;
+  const int rx = xx < W ? xx : 2 * (W - 1) - xx;
+  y[i] = x[(pl * H + ry) * W + rx];
+}
+
+// tiles[(t*B + b), c, :, :] = x[b, c, hs[t/nw] : +crop, ws[t%nw] : +crop]   (tile-major like the
+// reference's list of [B,C,crop,crop] crops, row starts outer, column starts inner)
+__global__ __launch_bounds__(256) void split_tiles_kernel(const float* __restrict__ x, float* __restrict__ tiles,
+                                                          TileGrid g, int B, int C, int H, int W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_tile = (long)B * C * g.crop * g.crop;
+  const long n = per_tile * g.nh * g.nw;
+  if (i >= n) return;
+  const int xx = (int)(i % g.crop);
+  long t = i / g.crop;
+  const int yy = (int)(t % g.crop);
+  t /= g.crop;
+  const int c = (int)(t % C);
+  t /= C;
+  const int b = (int)(t % B);
+  const int tile = (int)(t / B);
+  const int hs = g.hs[tile / g.nw], ws = g.ws[tile % g.nw];
+  tiles[i] = x[(((long)b * C + c) * H + hs + yy) * W + ws + xx];
+}
+
+// out[b,c,y,x] = (sum over the tiles covering (y,x), in tile order) / (their count): the reference
+// accumulates scoremap * tile with scoremap == 1 and divides by the accumulated score
+__global__ __launch_bounds__(256) void merge_tiles_kernel(const float* __restrict__ tiles, float* __restrict__ out,
+                                                          TileGrid g, int B, int C, int H, int W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)B * C * H * W;
+  if (i >= n) return;
+  const int xx = (int)(i % W);
+  long t = i / W;
+  const int yy = (int)(t % H);
+  t /= H;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  float sum = 0.f, cnt = 0.f;
+  for (int ih = 0; ih < g.nh; ++ih) {
+    const int dy = yy - g.hs[ih];
+    if (dy < 0 || dy >= g.crop) continue;
+    for (int iw = 0; iw < g.nw; ++iw) {
+      const int dx = xx - g.ws[iw];
+      if (dx < 0 || dx >= g.crop) continue;
+      const long tile = (long)ih * g.nw + iw;
+      sum += tiles[(((tile * B + b) * C + c) * g.crop + dy) * g.crop + dx];
+      cnt += 1.0f;
+    }
+  }
+  out[i] = sum / cnt;
+}
+
+// y[b, yy, xx, c] = uint8(rint(clamp(x[b, c, yy, xx], 0, 1) * 255)) for yy < h, xx < w
+// (crop to the unpadded size, clamp, NCHW -> NHWC, skimage img_as_ubyte: float32 multiply, round
+// half to even)
+__global__ __launch_bounds__(256) void crop_clamp_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ y,
+                                                            int B, int C, int H, int W, int h, int w) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)B * h * w * C;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  long t = i / C;
+  const int xx = (int)(t % w);
+  t /= w;
+  const int yy = (int)(t % h);
+  const int b = (int)(t / h);
+  float v = x[(((long)b * C + c) * H + yy) * W + xx];
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  y[i] = (unsigned char)rintf(v * 255.0f);
+}
+
+// same without the byte conversion: y[b,c,yy,xx] = clamp(x[b,c,yy,xx], 0, 1), cropped
+__global__ __launch_bounds__(256) void crop_clamp_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         long planes, int H, int W, int h, int w) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = planes * h * w;
+  if (i >= n) return;
+  const int xx = (int)(i % w);
+  const long t = i / w;
+  const int yy = (int)(t % h);
+  const long pl = t / h;
+  y[i] = fminf(fmaxf(x[(pl * H + yy) * W + xx], 0.f), 1.f);
+}
+
+static unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
+
+void launch_reflect_pad(const float* x, float* y, int B, int C, int H, int W, int pad_bottom, int pad_right,
+                        hipStream_t s) {
+  JIRF_REQUIRE(pad_bottom >= 0 && pad_right >= 0 && pad_bottom < H && pad_right < W, JIRF_EINVAL,
+               "reflect pad (%d, %d) must be smaller than the image %dx%d", pad_bottom, pad_right, H, W);
+  const int Ho = H + pad_bottom, Wo = W + pad_right;
+  const long planes = (long)B * C, n = planes * Ho * Wo;
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, y, H, W, Ho, Wo, planes);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+static void check_grid(const TileGrid& g, int H, int W) {
+  JIRF_REQUIRE(g.crop > 0 && g.crop <= H && g.crop <= W, JIRF_EINVAL, "tile %d does not fit %dx%d", g.crop, H, W);
+  JIRF_REQUIRE(g.nh >= 1 && g.nh <= TILE_GRID_MAX && g.nw >= 1 && g.nw <= TILE_GRID_MAX, JIRF_EINVAL,
+               "tile grid %dx%d (at most %d starts per axis)", g.nh, g.nw, TILE_GRID_MAX);
+  for (int i = 0; i < g.nh; ++i)
+    JIRF_REQUIRE(g.hs[i] >= 0 && g.hs[i] + g.crop <= H, JIRF_EINVAL, "row start %d out of range", g.hs[i]);
+  for (int i = 0; i < g.nw; ++i)
+    JIRF_REQUIRE(g.ws[i] >= 0 && g.ws[i] + g.crop <= W, JIRF_EINVAL, "column start %d out of range", g.ws[i]);
+}
+
+void launch_split_tiles(const float* x, float* tiles, const TileGrid& g, int B, int C, int H, int W, hipStream_t s) {
+  check_grid(g, H, W);
+  const long n = (long)B * C * g.crop * g.crop * g.nh * g.nw;
+  hipLaunchKernelGGL(split_tiles_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, tiles, g, B, C, H, W);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+void launch_merge_tiles(const float* tiles, float* out, const TileGrid& g, int B, int C, int H, int W, hipStream_t s) {
+  check_grid(g, H, W);
+  // every pixel must be covered, or the reference's division by the score is 0 / 0
+  auto covered = [&](const int* st, int n, int L) {
+    std::vector<char> hit(L, 0);
+    for (int i = 0; i < n; ++i)
+      for (int d = 0; d < g.crop; ++d) hit[st[i] + d] = 1;
+    for (char c : hit)
+      if (!c) return false;
+    return true;
+  };
+  JIRF_REQUIRE(covered(g.hs, g.nh, H) && covered(g.ws, g.nw, W), JIRF_EINVAL, "the tiles do not cover the image");
+  const long n = (long)B * C * H * W;
+  hipLaunchKernelGGL(merge_tiles_kernel, dim3(blocks_for(n)), dim3(256), 0, s, tiles, out, g, B, C, H, W);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+void launch_crop_clamp(const float* x, void* y, int B, int C, int H, int W, int h, int w, bool to_u8, hipStream_t s) {
+  JIRF_REQUIRE(h > 0 && w > 0 && h <= H && w <= W, JIRF_EINVAL, "crop %dx%d of %dx%d", h, w, H, W);
+  const long n = (long)B * C * h * w;
+  if (to_u8)
+    hipLaunchKernelGGL(crop_clamp_u8_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, static_cast<unsigned char*>(y),
+                       B, C, H, W, h, w);
+  else
+    hipLaunchKernelGGL(crop_clamp_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, static_cast<float*>(y), (long)B * C,
+                       H, W, h, w);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace jirf

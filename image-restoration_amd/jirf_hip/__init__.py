@@ -62,6 +62,11 @@ SIGNATURES = {
     "jirf_op_conv3x3": (_i, [_fp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_dwconv3x3": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "jirf_op_reflect_pad": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "jirf_op_split_tiles": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "jirf_op_merge_tiles": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "jirf_op_crop_clamp": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "jirf_op_crop_clamp_u8": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_hint_attention_core": (_i, [_fp, _vp, _fp, _i, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
 }
 

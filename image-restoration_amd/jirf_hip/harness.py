@@ -1,0 +1,145 @@
+"""Image plumbing of the reference's test scripts on the device (same function names and argument
+meaning as Deraining/test_rain100L.py:31-75,147-190), through the C ABI of libjirf_hip.  torch is
+used for device memory only; there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import check, lib
+
+_FP = C.POINTER(C.c_float)
+
+
+def _ptr(t: torch.Tensor):
+    return C.cast(t.data_ptr(), _FP)
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev(x: torch.Tensor) -> torch.Tensor:
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        raise TypeError("expected a float32 NCHW tensor on the GPU")
+    return x.contiguous()
+
+
+def pad_amounts(h: int, w: int, factor: int = 8) -> Tuple[int, int]:
+    """test_rain100L.py:148-151."""
+    H, W = ((h + factor) // factor) * factor, ((w + factor) // factor) * factor
+    return (H - h if h % factor != 0 else 0), (W - w if w % factor != 0 else 0)
+
+
+def pad_to_factor(x: torch.Tensor, factor: int = 8) -> torch.Tensor:
+    """test_rain100L.py:147-152: reflect-pad bottom / right to a multiple of `factor`."""
+    x = _dev(x)
+    b, c, h, w = x.shape
+    padh, padw = pad_amounts(h, w, factor)
+    if padh == 0 and padw == 0:
+        return x
+    y = torch.empty((b, c, h + padh, w + padw), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().jirf_op_reflect_pad(_ptr(x), _ptr(y), b, c, h, w, padh, padw, _stream(x)))
+    return y
+
+
+def tile_starts(length: int, crop_size: int, overlap_size: int) -> List[int]:
+    """test_rain100L.py:33-36."""
+    if crop_size <= overlap_size:
+        raise ValueError("crop_size must exceed overlap_size")
+    if crop_size > length:
+        raise ValueError(f"tile {crop_size} does not fit a side of {length}")
+    starts = list(range(0, length, crop_size - overlap_size))
+    while starts and starts[-1] + crop_size >= length:
+        starts.pop()
+    starts.append(length - crop_size)
+    return starts
+
+
+def _grid(starts: Sequence[Tuple[int, int]]):
+    hs = sorted({s[0] for s in starts}, key=[s[0] for s in starts].index)
+    ws = sorted({s[1] for s in starts}, key=[s[1] for s in starts].index)
+    if [(a, b) for a in hs for b in ws] != [tuple(s) for s in starts]:
+        raise ValueError("starts must be the row-major product of row starts and column starts")
+    return np.asarray(hs, np.int32), np.asarray(ws, np.int32)
+
+
+def splitimage(imgtensor: torch.Tensor, crop_size: int = 128, overlap_size: int = 64):
+    """test_rain100L.py:31-48.  Returns (split_data, starts); split_data is a list of
+    [B,C,crop,crop] views of ONE device tensor [n_tiles*B, C, crop, crop] (attribute `.stacked` of
+    the list) so the tiles can go through the network as a batch."""
+    x = _dev(imgtensor)
+    b, c, h, w = x.shape
+    hs = np.asarray(tile_starts(h, crop_size, overlap_size), np.int32)
+    ws = np.asarray(tile_starts(w, crop_size, overlap_size), np.int32)
+    n = len(hs) * len(ws)
+    tiles = torch.empty((n * b, c, crop_size, crop_size), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().jirf_op_split_tiles(_ptr(x), _ptr(tiles), b, c, h, w, crop_size, hs.ctypes.data, len(hs),
+                                        ws.ctypes.data, len(ws), _stream(x)))
+    split = TileList(tiles[i * b:(i + 1) * b] for i in range(n))
+    split.stacked = tiles
+    return split, [(int(a), int(d)) for a in hs for d in ws]
+
+
+class TileList(list):
+    stacked: torch.Tensor = None
+
+
+def mergeimage(split_data, starts, crop_size: int = 128, resolution=(1, 3, 128, 128)) -> torch.Tensor:
+    """test_rain100L.py:65-75 with the uniform score map the scripts use: mean blend in list order."""
+    b, c, h, w = (int(v) for v in resolution)
+    hs, ws = _grid(starts)
+    stacked = getattr(split_data, "stacked", None)
+    if stacked is None or stacked.shape[0] != len(starts) * b:
+        stacked = torch.cat([_dev(t) for t in split_data], dim=0)
+    stacked = _dev(stacked)
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=stacked.device)
+    with torch.cuda.device(stacked.device):
+        check(lib().jirf_op_merge_tiles(_ptr(stacked), _ptr(out), b, c, h, w, crop_size, hs.ctypes.data, len(hs),
+                                        ws.ctypes.data, len(ws), _stream(stacked)))
+    return out
+
+
+def crop_clamp(restored: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """test_rain100L.py:171-175: unpad and clamp to [0, 1]."""
+    x = _dev(restored)
+    b, c, H, W = x.shape
+    y = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().jirf_op_crop_clamp(_ptr(x), _ptr(y), b, c, H, W, h, w, _stream(x)))
+    return y
+
+
+def to_uint8_image(restored: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """test_rain100L.py:171-190: unpad, clamp, NHWC, img_as_ubyte.  Returns uint8 [B,h,w,C] on the GPU."""
+    x = _dev(restored)
+    b, c, H, W = x.shape
+    y = torch.empty((b, h, w, c), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().jirf_op_crop_clamp_u8(_ptr(x), C.c_void_p(y.data_ptr()), b, c, H, W, h, w, _stream(x)))
+    return y
+
+
+def restore_image(net, img: torch.Tensor, factor: int = 8, crop_size: int = None, overlap_size: int = None,
+                  tile_batch: int = 16) -> torch.Tensor:
+    """One image through a test script's loop body (test_rain100L.py:147-190): pad, restore (whole
+    image, or `crop_size` tiles with `overlap_size` overlap as the FPro / GoPro branches do),
+    unpad, clamp.  img: [1,3,h,w] float32 on the GPU; returns [1,3,h,w]."""
+    x = _dev(img)
+    h, w = x.shape[2], x.shape[3]
+    xp = pad_to_factor(x, factor)
+    if crop_size is None:
+        restored = net(xp)
+    else:
+        split, starts = splitimage(xp, crop_size, overlap_size)
+        tiles = split.stacked
+        outs = [net(tiles[i:i + tile_batch]) for i in range(0, tiles.shape[0], tile_batch)]
+        done = TileList()
+        done.stacked = torch.cat(outs, dim=0)
+        restored = mergeimage(done, starts, crop_size, tuple(xp.shape))
+    return crop_clamp(restored, h, w)

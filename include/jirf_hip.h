@@ -164,6 +164,29 @@ int jirf_op_hint_attention_core(const float* qkv, const float* params_host, cons
                                 float* cache_out, int B, int C, int P, int batch_mode,
                                 void* stream);
 
+/* ---- script-level image plumbing of the test scripts, on the device (all pointers are device
+ *      pointers except the start lists; index / byte work, bit-exact) --------------------------- */
+
+/* nn.pad(input_, (0, pad_right, 0, pad_bottom), "reflect") of Deraining/test_rain100L.py:147-152
+ * (same lines in every <Task>/test_*.py): y [B,C,H+pad_bottom,W+pad_right]. */
+int jirf_op_reflect_pad(const float* x, float* y, int B, int C, int H, int W, int pad_bottom, int pad_right,
+                        void* stream);
+/* splitimage (test_rain100L.py:31-48): tiles [(nh*nw)*B, C, crop, crop], tile t = (row start
+ * t / nw, column start t % nw) as in the reference's list order; hstarts / wstarts are HOST int32
+ * arrays (at most 96 entries each). */
+int jirf_op_split_tiles(const float* x, float* tiles, int B, int C, int H, int W, int crop, const int32_t* hstarts,
+                        int nh, const int32_t* wstarts, int nw, void* stream);
+/* mergeimage with the uniform score map the scripts use (test_rain100L.py:51-75, is_mean=True):
+ * out [B,C,H,W] = sum of the covering tiles in list order / their count.  The tiles must cover
+ * the image. */
+int jirf_op_merge_tiles(const float* tiles, float* out, int B, int C, int H, int W, int crop, const int32_t* hstarts,
+                        int nh, const int32_t* wstarts, int nw, void* stream);
+/* restored[:, :, :h, :w] clamped to [0, 1] (test_rain100L.py:171-175): y [B,C,h,w]. */
+int jirf_op_crop_clamp(const float* x, float* y, int B, int C, int H, int W, int h, int w, void* stream);
+/* The same followed by .permute(0,2,3,1) and skimage img_as_ubyte (test_rain100L.py:176-190):
+ * y [B,h,w,C] uint8 = rint(clamp(x, 0, 1) * 255) (float32 product, round half to even). */
+int jirf_op_crop_clamp_u8(const float* x, uint8_t* y, int B, int C, int H, int W, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
