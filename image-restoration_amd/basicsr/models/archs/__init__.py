@@ -3,7 +3,7 @@ reference): `define_network(opt)` pops `type`, looks the class up among the `*_a
 instantiates it with the remaining options."""
 import importlib
 
-_ARCH_MODULE_NAMES = ["ast_arch", "astv2_arch", "hint_arch"]
+_ARCH_MODULE_NAMES = ["ast_arch", "astv2_arch", "fpro_arch", "hint_arch"]
 _arch_modules = [importlib.import_module(f"basicsr.models.archs.{n}") for n in _ARCH_MODULE_NAMES]
 
 

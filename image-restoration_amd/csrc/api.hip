@@ -77,6 +77,8 @@ jirf_net* jirf_net_create(const char* arch, const char* cfg_json, int device) {
       net = make_astv2_net(cfg);
     } else if (!std::strcmp(arch, "AST")) {
       net = make_ast_net(cfg);
+    } else if (!std::strcmp(arch, "FPro")) {
+      net = make_fpro_net(cfg);
     } else {
       // define_network raises ValueError("<type> is not found.") (archs/__init__.py:39-40)
       set_error("%s is not found.", arch);
@@ -117,7 +119,7 @@ int jirf_net_param_info(const jirf_net* net, int index, const char** key_out, in
     const Net* n = get(net);
     JIRF_REQUIRE(index >= 0 && index < (int)n->params.size(), JIRF_EINVAL, "param index %d out of range", index);
     const ParamSpec& p = n->params[index];
-    JIRF_REQUIRE(p.shape.size() <= 4, JIRF_EINVAL, "param rank > 4");
+    JIRF_REQUIRE(p.shape.size() <= 8, JIRF_EINVAL, "param rank > 8");
     if (key_out) *key_out = p.key.c_str();
     if (ndim_out) *ndim_out = (int)p.shape.size();
     if (shape_out)

@@ -82,6 +82,7 @@ struct GemmArgs {
   const float* wt;       // [Kpad][Mpad]
   long wt_bs;            // batch stride of wt (0: shared)
   const float* bias;     // [M] or null
+  long bias_bs = 0;      // > 0: one bias vector per image, bias + b * bias_bs
   TV x;                  // input activation
   TV y;                  // output
   // loader extras
@@ -118,6 +119,25 @@ int pack_wt_conv(const float* w, int M, int Cin, int ks, std::vector<float>& out
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s);
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s);
+// ---- FPro frequency-prompt operators (fpro_ops.hip) ------------------------------------------------
+struct DynFilterW {            // dynamic_filter_channel parameters, device pointers
+  const float *conv, *gate, *bn_w, *bn_b, *bn_mean, *bn_var;
+  int groups;
+};
+void launch_channel_mean(TV x, float* out, int B, int C, long P, hipStream_t s);
+// pooled [B][C], coeff [B][groups*9] are scratch; low / high [B][C][H*W]
+void launch_dynfilter(TV x, const DynFilterW& w, float* pooled, float* coeff, TV low, TV high, int B, int C,
+                      int H, int W, hipStream_t s);
+// x: planes at x + b * x_bs + c * x_cs (x_bs = 0 resizes one parameter map for every image)
+void launch_resize(const float* x, long x_bs, long x_cs, float* y, long y_bs, int B, int C, int Hi, int Wi, int Ho,
+                   int Wo, bool cubic, hipStream_t s);
+void launch_fspg_high(TV f, const float* k1, const float* b1, const float* k2, const float* b2, const float* wmap,
+                      TV y, int B, int C, int H, int W, hipStream_t s);
+void launch_cross_window_attention(TV q, TV kv, TV out, int B, int C, int heads, int H, int W, hipStream_t s);
+void launch_prompt_low(const float* mean, float hw, const float* Wb, const float* bb, const float* w00,
+                       float ifft_scale, const float* M, const float* b0, float* bias_out, int B, int C2, int C,
+                       hipStream_t s);
+
 // ---- script-level image plumbing (harness.hip) ---------------------------------------------------
 constexpr int TILE_GRID_MAX = 96;
 struct TileGrid {            // tiles = row starts x column starts, all of one square size
@@ -198,9 +218,12 @@ struct HeadAttnScratch {
 int head_attn_splits(int B, int C, int P);
 size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, HeadAttnScratch* out);
 // q, k: channel slices of the dw-conv output.  Leaves the per-image attention in sc.att_t.
+// ca_w == NULL: plain MDTA (softmax only, fpro_arch.py:128-144); otherwise ASTv2's sparse branch and
+// att_ca.  norm_add_eps > 0: rows are normalised as x / (||x|| + eps) (fpro_arch.py:10-12) instead
+// of x / max(||x||, tiny).
 void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const float* temperature,
                            const float* ca_w, const float* ca_b, const HeadAttnScratch& sc,
-                           hipStream_t s);
+                           hipStream_t s, float norm_add_eps = 0.f);
 
 // ---- 8x8 window attention (AST) ---------------------------------------------------------------
 struct WinAttnArgs {

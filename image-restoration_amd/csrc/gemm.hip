@@ -126,7 +126,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
 }
 
 template <int MODE>
-__device__ __forceinline__ void load_bias16(const GemmArgs& a, int rbase, int half, float* bias_r) {
+__device__ __forceinline__ void load_bias16(const GemmArgs& a_in, int b, int rbase, int half, float* bias_r) {
+  struct { const float* bias; int M; } a{a_in.bias ? a_in.bias + (long)b * a_in.bias_bs : nullptr, a_in.M};
   if (a.bias) {   // kernel argument: a scalar branch around the 16 loads
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
       if (rbase >= a.M) continue;   // wave-uniform: a padding tile
       float bias_r[16];
       if (rbase + 32 <= a.M) {
-        load_bias16<ST_FULL>(a, rbase, half, bias_r);
+        load_bias16<ST_FULL>(a, b, rbase, half, bias_r);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int cbase = n0 + wn * WN + j * 32;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
           else if (cbase < P) store_tile<EPI, ST_PRED>(a, b, acc[i][j], rbase, half, cbase + l31, bias_r);
         }
       } else {
-        load_bias16<ST_PRED>(a, rbase, half, bias_r);
+        load_bias16<ST_PRED>(a, b, rbase, half, bias_r);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int cbase = n0 + wn * WN + j * 32;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
     auto store_all = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
       constexpr int ST = FULL ? ST_FULL : ST_CLAMP;
-      load_bias16<ST>(a, m0, half, bias_r);
+      load_bias16<ST>(a, b, m0, half, bias_r);
 #pragma unroll
       for (int j = 0; j < TNW; ++j) {
         const int col = n0 + col_w + j * 32 + l31;

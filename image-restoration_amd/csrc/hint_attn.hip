@@ -607,7 +607,8 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
     const float* __restrict__ qk_part, const double* __restrict__ gram_part,
     const double* __restrict__ qsum_part, const float* __restrict__ q2_part,
     const float* __restrict__ k2_part, float* __restrict__ s_qk, float* __restrict__ rq,
-    float* __restrict__ rk, double* __restrict__ sim, int C, int P, int splits, int nsum, int ipg) {
+    float* __restrict__ rk, double* __restrict__ sim, int C, int P, int splits, int nsum, int ipg,
+    float norm_add) {
   extern __shared__ double dsm[];  // mean[C], dstd[C], red[256]
   double* mean = dsm;
   double* dstd = dsm + C;
@@ -627,8 +628,13 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
       q2 += q2_part[((long)b * splits + sp) * C + i];
       k2 += k2_part[((long)b * splits + sp) * C + i];
     }
-    rq[(long)b * C + i] = 1.0f / sqrtf(fmaxf(q2, NORM_EPS));
-    rk[(long)b * C + i] = 1.0f / sqrtf(fmaxf(k2, NORM_EPS));
+    if (norm_add > 0.f) {
+      rq[(long)b * C + i] = 1.0f / (sqrtf(q2) + norm_add);
+      rk[(long)b * C + i] = 1.0f / (sqrtf(k2) + norm_add);
+    } else {
+      rq[(long)b * C + i] = 1.0f / sqrtf(fmaxf(q2, NORM_EPS));
+      rk[(long)b * C + i] = 1.0f / sqrtf(fmaxf(k2, NORM_EPS));
+    }
   }
   if (sim == nullptr || b % ipg != 0) return;
   const int g = b / ipg;
@@ -1078,7 +1084,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     launch_reduce_slabs(sc.qk_part, sc.gram_part, sc.qsum_part, q2_part, k2_part, C, sh.splits, B, G, s);
     hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), smem, s, sc.qk_part, sc.gram_part,
                        sc.qsum_part, q2_part, k2_part, sc.s_qk, sc.rq, sc.rk, sim, C, P, sh.splits, 1,
-                       ipg);
+                       ipg, 0.f);
     JIRF_HIP_CHECK(hipGetLastError());
   }
   const float* pooled = nullptr;
@@ -1185,9 +1191,11 @@ __global__ __launch_bounds__(256) void head_attn_kernel(const HeadAttnArgs a) {
     const float v = S[(long)(off + r) * C + off + s] * a.rq[(long)b * C + off + r] *
                     a.rk[(long)b * C + off + s] * temp;
     S0[r * ld + s] = v;
-    const float p = fmaxf(v, 0.f);
-    const float p2 = p * p;
-    R[r * ld + s] = gelu_erf_a(p2) * p2;
+    if (a.ca_w) {
+      const float p = fmaxf(v, 0.f);
+      const float p2 = p * p;
+      R[r * ld + s] = gelu_erf_a(p2) * p2;
+    }
   }
   __syncthreads();
   {
@@ -1207,7 +1215,7 @@ __global__ __launch_bounds__(256) void head_attn_kernel(const HeadAttnArgs a) {
       for (int s = lane; s < c; s += 64) S0[r * ld + s] *= inv;
     }
   }
-  for (int e = tid; e < 2 * c * c; e += 256) {
+  for (int e = tid; a.ca_w && e < 2 * c * c; e += 256) {
     const int o = e / c, j = e - o * c;
     float z = a.ca_b ? a.ca_b[o] : 0.f;
     const float* __restrict__ w = a.ca_w + (long)o * c;
@@ -1225,7 +1233,7 @@ __global__ __launch_bounds__(256) void head_attn_kernel(const HeadAttnArgs a) {
     float v = 0.f;
     if (kr < off + c && m >= off && m < off + c) {
       const int col = kr - off, r = m - off;   // att_t[k = col][m = row] = A'[row][col]
-      v = S0[r * ld + col] * (1.0f + Z[col * ld + r]) + Z[(c + col) * ld + r];
+      v = a.ca_w ? S0[r * ld + col] * (1.0f + Z[col * ld + r]) + Z[(c + col) * ld + r] : S0[r * ld + col];
     }
     att_t[(long)kr * a.Mpad + m] = v;
   }
@@ -1254,7 +1262,7 @@ int head_attn_splits(int B, int C, int P) { return stats_splits((C + ST_T - 1) /
 
 void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const float* temperature,
                            const float* ca_w, const float* ca_b, const HeadAttnScratch& sc,
-                           hipStream_t s) {
+                           hipStream_t s, float norm_add_eps) {
   JIRF_REQUIRE(heads > 0 && C % heads == 0, JIRF_EINVAL, "head attention: C=%d is not divisible by heads=%d", C, heads);
   const int ch = C / heads;
   const size_t smem = (size_t)4 * ch * (ch + 1) * 4;
@@ -1277,7 +1285,7 @@ void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const flo
     Scope scope("head_reduce_rows", 1.0 * C * (double)C * splits * B, 4.0 * C * (double)C * splits * B, s);
     launch_reduce_slabs(sc.qk_part, nullptr, nullptr, sc.q2_part, sc.k2_part, C, splits, B, 0, s);
     hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), 0, s, sc.qk_part, nullptr, nullptr,
-                       sc.q2_part, sc.k2_part, sc.s_qk, sc.rq, sc.rk, nullptr, C, P, splits, 1, 1);
+                       sc.q2_part, sc.k2_part, sc.s_qk, sc.rq, sc.rk, nullptr, C, P, splits, 1, 1, norm_add_eps);
     JIRF_HIP_CHECK(hipGetLastError());
   }
   {

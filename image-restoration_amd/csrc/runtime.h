@@ -132,6 +132,7 @@ struct Net {
 std::unique_ptr<Net> make_hint_net(const Config& cfg);
 std::unique_ptr<Net> make_astv2_net(const Config& cfg);
 std::unique_ptr<Net> make_ast_net(const Config& cfg);
+std::unique_ptr<Net> make_fpro_net(const Config& cfg);
 
 // Uploads a host vector into a weight pool that lives as long as the net.
 struct WeightPool {

@@ -140,7 +140,7 @@ class Net:
         L = lib()
         out = []
         key = C.c_char_p()
-        shape = (C.c_int64 * 4)()
+        shape = (C.c_int64 * 8)()
         nd = C.c_int()
         for i in range(L.jirf_net_param_count(self._h)):
             check(L.jirf_net_param_info(self._h, i, C.byref(key), shape, C.byref(nd)))

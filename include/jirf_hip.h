@@ -1,6 +1,6 @@
 /*
  * libjirf_hip.so — C ABI of the MI355X (gfx950) inference forward of the JIRF
- * restoration networks (HINT, ASTv2, AST).
+ * restoration networks (HINT, ASTv2, AST, FPro).
  *
  * The reference has no FFI: the seam this library replaces is the Python class
  * contract of `network_g` (reference basicsr/models/archs/__init__.py:44-47
@@ -58,7 +58,7 @@ const char* jirf_last_error(void);
 /* Stands in for `cls(**opt)` of define_network (archs/__init__.py:22-47) with
  * arch in {"HINT" (ctor kwargs of hint_arch.py:495-508), "ASTv2"
  * (astv2_arch.py:303-315), "AST" (ast_arch.py:941-965; token_mlp "frfn", the
- * only feed-forward its configs use)}.  cfg_json is the `network_g` YAML block
+ * only feed-forward its configs use), "FPro" (fpro_arch.py:549-561)}.  cfg_json is the `network_g` YAML block
  * without `type`, as JSON.  Unknown arch: NULL + JIRF_ENOTFOUND; unknown
  * option: NULL + JIRF_EINVAL. */
 jirf_net* jirf_net_create(const char* arch, const char* cfg_json, int device);
@@ -74,7 +74,7 @@ int jirf_net_set_param(jirf_net* net, const char* key, const void* host_data, in
                        const int64_t* shape, int ndim);
 
 /* Number of parameter keys the network expects and the i-th key/shape (for
- * state_dict() and strict-load checks).  shape_out holds up to 4 dims. */
+ * state_dict() and strict-load checks).  shape_out must hold 8 dims. */
 int jirf_net_param_count(const jirf_net* net);
 int jirf_net_param_info(const jirf_net* net, int index, const char** key_out, int64_t* shape_out,
                         int* ndim_out);

@@ -223,3 +223,105 @@ def make_ast_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0) ->
         g.kernel(f"upsample_{i}.deconv.0.weight", (ci, co, 2, 2), fan_in=ci)
         g.vec(f"upsample_{i}.deconv.0.bias", co, 0.0, 0.05)
     return g.sd
+
+
+def make_fpro_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0,
+                    prompt_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """FPro state dict (fpro_arch.py:92-161,212-221,249-308,339-354,378-400,452-469,548-682
+    constructors).  The learned prompt maps (`FSPG_high.weight`, `FSPG_low.complex_weight`, 0.02 *
+    randn in the reference) are drawn with std `prompt_gain` so the prompt branches carry weight in
+    a parity test; BatchNorm running statistics are randomised like a trained checkpoint's."""
+    from .fpro_oracle import FILTER_GROUPS, default_config, prompt_plan, stage_plan
+    cfg = cfg or default_config()
+    g = _Gen(seed, gain)
+    dim, bias = cfg["dim"], cfg.get("bias", False)
+    with_bias_ln = cfg.get("ln_type", "WithBias") != "BiasFree"
+    ffn = cfg["ffn_expansion_factor"]
+    heads = cfg["heads"]
+    cin, cout = cfg.get("inp_channels", 3), cfg.get("out_channels", 3)
+
+    def conv(key, co, ci, k, b):
+        g.kernel(key + ".weight", (co, ci, k, k))
+        if b:
+            g.vec(key + ".bias", co, 0.0, 0.05)
+
+    def linear(key, co, ci):
+        g.kernel(key + ".weight", (co, ci))
+        g.vec(key + ".bias", co, 0.0, 0.05)
+
+    def ln(key, c):
+        g.vec(key + ".body.weight", c, 1.0, 0.1)
+        if with_bias_ln:
+            g.vec(key + ".body.bias", c, 0.0, 0.1)
+
+    for name, n, mult, hi, is_att in stage_plan(cfg):
+        c = dim * mult
+        for i in range(n):
+            pre = f"{name}.{i}"
+            if is_att:
+                ln(pre + ".norm1", c)
+                a = pre + ".attn"
+                g.uniform(a + ".temperature", (heads[hi], 1, 1), 0.5, 2.0)
+                conv(a + ".qkv", 3 * c, c, 1, bias)
+                g.kernel(a + ".qkv_dwconv.weight", (3 * c, 1, 3, 3))
+                if bias:
+                    g.vec(a + ".qkv_dwconv.bias", 3 * c, 0.0, 0.05)
+                conv(a + ".project_out", c, c, 1, bias)
+            ln(pre + ".norm2", c)
+            f = pre + ".ffn"
+            h = int(c * ffn)
+            conv(f + ".project_in", 2 * h, c, 1, bias)
+            g.kernel(f + ".dwconv.weight", (2 * h, 1, 3, 3))
+            if bias:
+                g.vec(f + ".dwconv.bias", 2 * h, 0.0, 0.05)
+            conv(f + ".project_out", c, h, 1, bias)
+    g.kernel("patch_embed.proj.weight", (dim, cin, 3, 3))
+    g.kernel("down1_2.body.0.weight", (dim // 2, dim, 3, 3))
+    g.kernel("down2_3.body.0.weight", (dim, 2 * dim, 3, 3))
+    g.kernel("up3_2.body.0.weight", (8 * dim, 4 * dim, 3, 3))
+    g.kernel("up2_1.body.0.weight", (4 * dim, 2 * dim, 3, 3))
+    conv("reduce_chan_level2", 2 * dim, 4 * dim, 1, bias)
+    if cfg.get("dual_pixel_task", False):
+        conv("skip_conv", 2 * dim, dim, 1, bias)
+    conv("output", cout, 2 * dim, 3, bias)
+
+    d = "splitFre.dyna_channel"
+    nf = FILTER_GROUPS * 9
+    g.kernel(d + ".conv.weight", (nf, dim, 1, 1))
+    # the pooled feature is small: scale the filter logits up so the 9 taps are visibly unequal
+    g.sd[d + ".conv.weight"] *= np.float32(8.0)
+    g.kernel(d + ".conv_gate.weight", (nf, nf, 1, 1))
+    g.vec(d + ".bn.weight", nf, 1.0, 0.2)
+    g.vec(d + ".bn.bias", nf, 0.0, 0.2)
+    g.vec(d + ".bn.running_mean", nf, 0.0, 0.2)
+    g.uniform(d + ".bn.running_var", (nf,), 0.5, 1.5)
+
+    for name, mult, res in prompt_plan(cfg):
+        c = dim * mult
+        conv(name + ".simple_Fusion", c, 2 * c, 1, True)
+        hi_ = name + ".FSPG_high"
+        # (x 30: the high-frequency prompt is a product of three small factors)
+        g.sd[hi_ + ".weight"] = (30.0 * prompt_gain * g.rng.standard_normal((1, dim, res, res))).astype(np.float32)
+        g.kernel(hi_ + ".body.0.weight", (dim, 1, 1, 3))
+        g.vec(hi_ + ".body.0.bias", dim, 0.0, 0.05)
+        g.kernel(hi_ + ".body.1.weight", (dim, 1, 3, 1))
+        g.vec(hi_ + ".body.1.bias", dim, 0.0, 0.05)
+        lo_ = name + ".FSPG_low"
+        g.sd[lo_ + ".complex_weight"] = (prompt_gain * g.rng.standard_normal((1, dim, res, res // 2 + 1, 2))).astype(np.float32)
+        g.kernel(lo_ + ".body.0.weight", (2 * dim, 2 * dim, 1, 1))
+        # the spectrum's DC term is a sum over all pixels: keep the gate's argument O(1)
+        g.sd[lo_ + ".body.0.weight"] *= np.float32(1e-3)
+        g.vec(lo_ + ".body.0.bias", 2 * dim, 0.0, 0.05)
+        mh = name + ".modulator_hi"
+        linear(mh + ".to_q.to_q", c, c)
+        linear(mh + ".to_kv.to_kv", 2 * c, dim)
+        g.sd[mh + ".to_kv.to_kv.weight"] *= np.float32(8.0)     # the prompt is small: let k, v depend on it
+        g.sd[mh + ".to_q.to_q.weight"] *= np.float32(3.0)       # and the softmax on q
+        g.kernel(mh + ".kv_dwconv.weight", (dim, 1, 3, 3))
+        linear(mh + ".project_out", c, c)
+        ml = name + ".modulator_lo"
+        g.uniform(ml + ".temperature", (2, 1, 1), 0.5, 2.0)
+        conv(ml + ".q", c, c, 1, False)
+        conv(ml + ".kv", 2 * c, dim, 1, False)
+        conv(ml + ".project_out", c, c, 1, False)
+    return g.sd
