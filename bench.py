@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--height", type=int, default=0, help="image height (default: --size)")
     ap.add_argument("--width", type=int, default=0, help="image width (default: --size)")
-    ap.add_argument("--arch", default="HINT", choices=["HINT", "ASTv2", "AST"],
+    ap.add_argument("--arch", default="HINT", choices=["HINT", "ASTv2", "AST", "FPro"],
                     help="network; the headline workload is HINT (the other two are parity configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -108,7 +108,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from oracle import hint_oracle as ho
-    from oracle.weights import make_hint_state, make_astv2_state, make_ast_state, synthetic_images
+    from oracle.weights import make_hint_state, make_astv2_state, make_ast_state, make_fpro_state, synthetic_images
     from basicsr.models.archs import define_network
 
     if args.arch == "HINT":
@@ -118,6 +118,10 @@ def main():
         from oracle import astv2_oracle as oracle_mod
         cfg = oracle_mod.default_config()
         sd = make_astv2_state(cfg, seed=1, gain=0.6)
+    elif args.arch == "FPro":
+        from oracle import fpro_oracle as oracle_mod
+        cfg = oracle_mod.default_config()
+        sd = make_fpro_state(cfg, seed=1, gain=0.6)
     else:
         from oracle import ast_oracle as oracle_mod
         cfg = oracle_mod.default_config()
@@ -231,6 +235,8 @@ def main():
             ho.hint_forward(sd, xs, cfg, None)
         elif args.arch == "ASTv2":
             oracle_mod.astv2_forward(sd, xs, cfg)
+        elif args.arch == "FPro":
+            oracle_mod.fpro_forward(sd, xs, cfg)
         else:
             oracle_mod.ast_forward(sd, xs, cfg)
         dt = time.perf_counter() - t0

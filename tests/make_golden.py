@@ -15,9 +15,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import ast_oracle, astv2_oracle  # noqa: E402
+from oracle import ast_oracle, astv2_oracle, fpro_oracle  # noqa: E402
 from oracle import hint_oracle as ho  # noqa: E402
-from oracle.weights import make_ast_state, make_astv2_state, make_hint_state, synthetic_images  # noqa: E402
+from oracle.weights import (make_ast_state, make_astv2_state, make_fpro_state, make_hint_state,  # noqa: E402
+                            synthetic_images)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -31,6 +32,10 @@ ASTV2_SMALL = dict(inp_channels=3, out_channels=3, dim=24, num_blocks=[1, 2, 2],
 # AST: the reference default constructor with one block per stage except two at the first (so a
 # shifted block exists); 128 x 128 is the smallest input its four scales of 8 x 8 windows take
 AST_SHALLOW = dict(ast_oracle.default_config(), depths=[2, 1, 1, 1, 1, 1, 1, 1, 1])
+
+
+FPRO_SMALL = dict(inp_channels=3, out_channels=3, dim=16, num_blocks=[1, 2, 2], num_refinement_blocks=1,
+                  heads=[1, 2, 4], ffn_expansion_factor=2.66, bias=False, ln_type="WithBias", dual_pixel_task=False)
 
 
 def weights_digest(sd):
@@ -80,6 +85,12 @@ def ast_case(name, cfg, seed, side, b=1):
                 synthetic_images(b, side, side, seed=seed + 10), seed)
 
 
+def fpro_case(name, cfg, seed, h, w, b=1):
+    sd = make_fpro_state(cfg, seed=seed, gain=0.6)
+    simple_case(name, lambda s_, x_: fpro_oracle.fpro_forward(s_, x_, cfg), sd,
+                synthetic_images(b, h, w, seed=seed + 10, sigma=25), seed)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     hint_case("hint_small_48x64", HINT_SMALL, 3, 48, 64)
@@ -88,3 +99,4 @@ if __name__ == "__main__":
     hint_case("hint_small_modgain_32x48", HINT_SMALL, 5, 32, 48, mod_gain=3.0)
     astv2_case("astv2_small_40x56", ASTV2_SMALL, 7, 40, 56, b=2)
     ast_case("ast_shallow_128", AST_SHALLOW, 8, 128)
+    fpro_case("fpro_small_64x96", FPRO_SMALL, 9, 64, 96)

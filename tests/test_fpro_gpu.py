@@ -71,3 +71,25 @@ def test_rejects_bad_shapes():
     net = _build(SMALL, make_fpro_state(SMALL, seed=1))
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 48, 64).cuda())
+
+
+def test_sots_sized_image_through_the_tiled_script_path():
+    """A 620 x 460 image the way Dehaze/test_SOTS.py runs FPro: pad to 624 x 464, 20 tiles of 256 x 256
+    with overlap 158, one forward per tile, mean blend, unpad, clamp (test_rain100L.py:156-175 has the
+    same branch).  The device composite equals the same steps done with the oracle's plumbing around
+    the same network."""
+    from jirf_hip import harness as hh
+    from oracle import harness_oracle as ho
+    cfg = dict(SMALL)
+    net = _build(cfg, make_fpro_state(cfg, seed=13, gain=0.6))
+    net.batch_mode = "per_image"
+    x = synthetic_images(1, 460, 620, seed=54, sigma=10)
+    got = hh.restore_image(net, torch.from_numpy(x).cuda(), crop_size=256, overlap_size=158, tile_batch=8).cpu().numpy()
+    xp = ho.pad_to_factor(x)
+    split, starts = ho.splitimage(xp, 256, 158)
+    assert xp.shape[2:] == (464, 624) and len(split) == 20
+    outs = [net(torch.from_numpy(np.ascontiguousarray(t)).cuda()).cpu().numpy() for t in split]
+    want = ho.crop_clamp(ho.mergeimage(outs, starts, 256, xp.shape), 460, 620)
+    # tiles run 8 at a time here and one at a time there: the split-K schedule of the channel
+    # attention depends on the batch, so sums differ in their last bits
+    assert max_abs(got, want) < 1e-5

@@ -6,9 +6,9 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.weights import make_ast_state, make_astv2_state, make_hint_state
+from oracle.weights import make_ast_state, make_astv2_state, make_fpro_state, make_hint_state
 from tests.gpu_util import max_abs
-from tests.make_golden import AST_SHALLOW, ASTV2_SMALL, HINT_SMALL, weights_digest
+from tests.make_golden import AST_SHALLOW, ASTV2_SMALL, FPRO_SMALL, HINT_SMALL, weights_digest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -68,4 +68,12 @@ def test_ast_golden():
     sd = make_ast_state(AST_SHALLOW, seed=int(g["seed"]), gain=0.5)
     assert weights_digest(sd) == str(g["weights_sha256"])
     y = _net("AST", AST_SHALLOW, sd)(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    assert max_abs(y, g["y"]) < TOL
+
+
+def test_fpro_golden():
+    g = np.load(os.path.join(GOLD, "fpro_small_64x96.npz"))
+    sd = make_fpro_state(FPRO_SMALL, seed=int(g["seed"]), gain=0.6)
+    assert weights_digest(sd) == str(g["weights_sha256"])
+    y = _net("FPro", FPRO_SMALL, sd)(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
     assert max_abs(y, g["y"]) < TOL

@@ -183,3 +183,76 @@ def test_ast_window_partition_round_trip():
     assert w.shape == (2 * 2 * 3, 8, 8, 3)
     assert torch.equal(w[4], x[0, 8:16, 8:16])            # window (1, 1) of image 0
     assert torch.equal(so.window_reverse(w, 8, 16, 24), x)
+
+
+# ---- FPro oracle ------------------------------------------------------------------------------------
+def test_fpro_oracle_reproduces_golden():
+    from oracle import fpro_oracle
+    from oracle.weights import make_fpro_state
+    from tests.make_golden import FPRO_SMALL
+    g = np.load(os.path.join(GOLD, "fpro_small_64x96.npz"))
+    sd = make_fpro_state(FPRO_SMALL, seed=int(g["seed"]), gain=0.6)
+    assert weights_digest(sd) == str(g["weights_sha256"])
+    y = fpro_oracle.fpro_forward(sd, torch.from_numpy(g["x"]), FPRO_SMALL).numpy()
+    assert np.abs(y - g["y"]).max() < 2e-5
+
+
+def test_fpro_dynamic_filter_is_a_normalised_low_pass():
+    """The nine taps of every (image, group) are a softmax: a constant image passes through the
+    low branch unchanged and leaves a zero high branch (fpro_arch.py:355-375)."""
+    from oracle import fpro_oracle as fo
+    from oracle.weights import make_fpro_state
+    from tests.make_golden import FPRO_SMALL
+    p = {k: torch.from_numpy(v) for k, v in make_fpro_state(FPRO_SMALL, seed=3).items()}
+    x = torch.full((2, 16, 12, 20), 0.7)
+    low, high = fo.dynamic_filter(p, "splitFre.dyna_channel", x)
+    assert float((low - x).abs().max()) < 1e-6 and float(high.abs().max()) < 1e-6
+    # literal loop form on a random image: reflection padding, per-group taps
+    x = torch.randn(1, 16, 6, 7, generator=torch.Generator().manual_seed(0))
+    low, _ = fo.dynamic_filter(p, "splitFre.dyna_channel", x)
+    pooled = x.mean(dim=(2, 3))[0]
+    f = p["splitFre.dyna_channel.conv.weight"][:, :, 0, 0] @ pooled
+    f = f * torch.sigmoid(p["splitFre.dyna_channel.conv_gate.weight"][:, :, 0, 0] @ f)
+    f = (f - p["splitFre.dyna_channel.bn.running_mean"]) / torch.sqrt(p["splitFre.dyna_channel.bn.running_var"] + 1e-5)
+    f = f * p["splitFre.dyna_channel.bn.weight"] + p["splitFre.dyna_channel.bn.bias"]
+    taps = f.reshape(8, 9).softmax(dim=1)
+    refl = lambda i, n: -i if i < 0 else (2 * (n - 1) - i if i >= n else i)
+    for c in (0, 5, 15):
+        for (yy, xx) in ((0, 0), (5, 6), (2, 3)):
+            want = sum(float(taps[c // 2, (dy + 1) * 3 + dx + 1]) * float(x[0, c, refl(yy + dy, 6), refl(xx + dx, 7)])
+                       for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+            assert abs(float(low[0, c, yy, xx]) - want) < 1e-5
+
+
+def test_fpro_high_fusion_flatten_is_the_literal_reshape():
+    """(attn @ v).transpose(-2, -1).reshape(B_, N, C) (fpro_arch.py:331-332): flat element
+    (head * hd + d) * N + n of a window lands on token f // C, channel f % C."""
+    from oracle import fpro_oracle as fo
+    B_, heads, N, hd = 3, 2, 64, 4
+    C = heads * hd
+    o = torch.arange(B_ * heads * N * hd, dtype=torch.float32).reshape(B_, heads, N, hd)
+    flat = o.transpose(-2, -1).reshape(B_, N, C)
+    for (b, h, n, d) in ((0, 0, 0, 0), (1, 1, 17, 3), (2, 0, 63, 2)):
+        f = (h * hd + d) * N + n
+        assert float(flat[b, f // C, f % C]) == float(o[b, h, n, d])
+
+
+def test_fpro_low_prompt_mean_is_the_dc_term():
+    """mean over pixels of ifft2(Y).real == Re(Y[0, 0]) / (H W): what lets the device path skip the FFT."""
+    from oracle import fpro_oracle as fo
+    from oracle.weights import make_fpro_state
+    from tests.make_golden import FPRO_SMALL
+    p = {k: torch.from_numpy(v) for k, v in make_fpro_state(FPRO_SMALL, seed=4).items()}
+    low = torch.rand(2, 16, 64, 96, generator=torch.Generator().manual_seed(1))
+    H, W = 32, 48
+    y = fo.fspg_low(p, "prompt_d2.FSPG_low", low, H, W, fo.FproSwitches())
+    r = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)
+    s = r.sum(dim=(2, 3))                                                    # [B, 16] = Re Y[0,0], Im = 0
+    yf = torch.cat([s, torch.zeros_like(s)], dim=1)
+    a = fo.gelu(yf @ p["prompt_d2.FSPG_low.body.0.weight"][:, :, 0, 0].T + p["prompt_d2.FSPG_low.body.0.bias"])
+    re = (yf * a)[:, :16]
+    wr = torch.nn.functional.interpolate(p["prompt_d2.FSPG_low.complex_weight"][..., 0], size=(H, W), mode="bilinear",
+                                         align_corners=False)[0, :, 0, 0]
+    want = re * wr / (H * W)
+    got = y.mean(dim=(2, 3))
+    assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max())
