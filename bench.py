@@ -107,25 +107,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from oracle import hint_oracle as ho
-    from oracle.weights import make_hint_state, make_astv2_state, make_ast_state, make_fpro_state, synthetic_images
+    from jirf_hip.synthetic import default_config, make_state, synthetic_images
     from basicsr.models.archs import define_network
 
-    if args.arch == "HINT":
-        cfg = ho.default_config()
-        sd = make_hint_state(cfg, seed=1, gain=0.6)
-    elif args.arch == "ASTv2":
-        from oracle import astv2_oracle as oracle_mod
-        cfg = oracle_mod.default_config()
-        sd = make_astv2_state(cfg, seed=1, gain=0.6)
-    elif args.arch == "FPro":
-        from oracle import fpro_oracle as oracle_mod
-        cfg = oracle_mod.default_config()
-        sd = make_fpro_state(cfg, seed=1, gain=0.6)
-    else:
-        from oracle import ast_oracle as oracle_mod
-        cfg = oracle_mod.default_config()
-        sd = make_ast_state(cfg, seed=1, gain=0.5)
+    cfg = default_config(args.arch)
+    sd = make_state(args.arch, cfg, seed=1)
     net = define_network(dict(cfg, type=args.arch))
     net.load_state_dict(sd)
     net.cuda(local_rank).eval()
@@ -229,19 +215,28 @@ def main():
         # bounded sample: one 256x256 image through the oracle on the host cores of this box
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
         torch.set_num_threads(cores)
-        xs = x[:1].cpu()
-        t0 = time.perf_counter()
+        xh = x.cpu()
+        # the only place the benchmark touches oracle/: the CPU restatement, as the reported baseline
         if args.arch == "HINT":
-            ho.hint_forward(sd, xs, cfg, None)
+            from oracle.hint_oracle import hint_forward as _f
+            oracle_forward = lambda sd_, x_, cfg_: _f(sd_, x_, cfg_, None)
         elif args.arch == "ASTv2":
-            oracle_mod.astv2_forward(sd, xs, cfg)
+            from oracle.astv2_oracle import astv2_forward as oracle_forward
         elif args.arch == "FPro":
-            oracle_mod.fpro_forward(sd, xs, cfg)
+            from oracle.fpro_oracle import fpro_forward as oracle_forward
         else:
-            oracle_mod.ast_forward(sd, xs, cfg)
+            from oracle.ast_oracle import ast_forward as oracle_forward
+        # bounded sample: images of the benchmark batch, one B = 1 call each (what the step does per
+        # image), until about 12 s of CPU work or the batch is used up
+        t0 = time.perf_counter()
+        n_img = 0
+        while n_img < B and (n_img == 0 or time.perf_counter() - t0 < 12.0):
+            oracle_forward(sd, xh[n_img:n_img + 1], cfg)
+            n_img += 1
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(Hh * Ww / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
-                               "sample": f"1 image {Ww}x{Hh} through the oracle/ restatement of {args.arch} (torch-CPU fp32), {dt:.1f} s"}
+        out["cpu_baseline"] = {"value": round(n_img * Hh * Ww / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
+                               "sample": f"{n_img} image(s) {Ww}x{Hh} of the benchmark batch through the oracle/ restatement "
+                                         f"of {args.arch} (torch-CPU fp32, {cores} threads), {dt:.1f} s"}
 
     if use_dist:
         dist.barrier()
