@@ -474,7 +474,10 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   // ---- output tiles -----------------------------------------------------------------------------
   const float* __restrict__ wt = a.wt + (long)b * a.wt_bs;
   const int n_mt = (M + 31) >> 5;
-  const int n_items = n_mt * NG;
+  // small grids split the output rows over gridDim.y workgroups (each reloads the pixel tile)
+  const int mt_per = (n_mt + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int item_lo = min((int)blockIdx.y * mt_per, n_mt) * NG;
+  const int n_items = min(((int)blockIdx.y + 1) * mt_per, n_mt) * NG;
   const int nsteps = Kp >> 1;
   const int epi = a.epi;
   // A-fragment address of an item: rows past Mpad do not exist in the packed weights, so the
@@ -486,12 +489,12 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   // nsteps is a multiple of XS_ABATCH (K is padded to 16): every load below is unconditional, and
   // the batch fetched during an item's last batch already belongs to the wave's next item
   float a_cur[XS_ABATCH], a_nxt[XS_ABATCH];
-  if (wave < n_items) {
-    const float* __restrict__ ap0 = a_ptr(wave);
+  if (item_lo + wave < n_items) {
+    const float* __restrict__ ap0 = a_ptr(item_lo + wave);
 #pragma unroll
     for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = ap0[(long)(2 * i) * a.Mpad];
   }
-  for (int item = wave; item < n_items; item += 4) {
+  for (int item = item_lo + wave; item < n_items; item += 4) {
     const int mt = item / NG, ng = item - mt * NG;
     const int m0 = mt * 32;
     const int col_w = ng * TNW * 32;            // first pixel of this wave's group inside the tile
@@ -555,7 +558,11 @@ static void launch_xs(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
   const int tiles_n = (a.P + BN - 1) / BN;
   const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
   const size_t smem = ((size_t)Kp * BN + 2 * BN) * sizeof(float);
-  const dim3 grid((unsigned)(tiles_n * a.B)), block(256);
+  // fewer workgroups than twice the CUs: split the output-row tiles over gridDim.y (at least 4 per part)
+  const int n_mt = (a.M + 31) / 32;
+  int msplit = 1;
+  while ((long)tiles_n * a.B * msplit < 512 && n_mt / (msplit * 2) >= 4) msplit *= 2;
+  const dim3 grid((unsigned)(tiles_n * a.B), (unsigned)msplit), block(256);
 #define JIRF_XS_CASE(LD, V)                                                                        \
   do {                                                                                             \
     static bool attr = false;                                                                      \
