@@ -759,6 +759,8 @@ __global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs 
   // ---- gather + scale: X[r][s] = S[perm r][perm s] * rq[perm r] * rk[perm s] * T ----
   const float temp = a.temperature[gi];
   const float* __restrict__ S = a.s_qk + (long)b * C * C;
+  // (unrolled: the gathers are dependent-latency bound otherwise, one global round trip per element)
+#pragma unroll 8
   for (int e = tid; e < c * c; e += 256) {
     const int r = e / c, s = e - r * c;
     const int ci = perm[off + r], cj = perm[off + s];
@@ -846,6 +848,7 @@ __global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs
   float* __restrict__ att_nat = a.att_nat + (long)b * C * C;
   const float* __restrict__ pg = a.pooled_g + (long)g * a.psum + a.poff[gi];
 
+#pragma unroll 4
   for (int e = tid; e < c * GA_JC; e += 256) {
     const int r = e >> 5, jj = e & 31;
     float x = 0.f, xp = 0.f;
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* __restrict__ ap = Wt + (long)half * mp2 + mt * 32 + l31;
       const float* __restrict__ bp = XP + half * GA_LD + l31;
-#pragma unroll 4
+#pragma unroll 16
       for (int k0 = 0; k0 < c; k0 += 2)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(long)k0 * mp2], bp[k0 * GA_LD], acc, 0, 0, 0);
 #pragma unroll
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* __restrict__ ap = Wt + (long)half * mp1 + mt * 32 + l31;
       const float* __restrict__ bp = Ys + half * GA_LD + l31;
-#pragma unroll 4
+#pragma unroll 16
       for (int k0 = 0; k0 < c; k0 += 2)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(long)k0 * mp1], bp[k0 * GA_LD], acc, 0, 0, 0);
       if (l31 < nj) {

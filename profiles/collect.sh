@@ -3,7 +3,7 @@
 #   bash profiles/collect.sh <tag>        (tag e.g. r01)
 # 1. rocprofv3 --kernel-trace --stats over the default benchmark command (short step count)
 # 2. over the dominant launch shape alone (profiles/pmc_op.py): two PMC passes (reads, writes:
-#    they do not fit one pass) and one kernel-trace pass
+#    they do not fit one pass), one SQ pass (MFMA busy and wait cycles) and one kernel-trace pass
 set -e
 tag=${1:-r01}
 out=gpurun_out/prof_$tag
@@ -12,5 +12,6 @@ export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o pmc -- python3 profiles/pmc_op.py
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o pmc -- python3 profiles/pmc_op.py
+timeout -s KILL 120 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/pmc_sq -o pmc -- python3 profiles/pmc_op.py
 timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $out/op_trace -o op -- python3 profiles/pmc_op.py
 find $out -type f | head -50

@@ -70,7 +70,20 @@ if os.path.exists(p_iso):
     iso = {"avg_ns": r[0], "launches": r[1],
            "note": "same launch shape run alone on N(0,1) inputs (profiles/pmc_op.py); the clock the chip holds, and "
                    "with it the duration, depends on the operand data, so this differs from the in-network launches"}
-res = {"isolated_kernel_trace": iso, "op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
+sq = None
+p_sq = os.path.join(src, "pmc_sq", "pmc_results.db")
+if os.path.exists(p_sq):
+    d = sqlite3.connect(p_sq)
+    q = ("select e.counter_name, avg(e.counter_value) from pmc_events e join kernels k on e.dispatch_id = k.dispatch_id "
+         "where k.name like '%gemm%' group by e.counter_name")
+    c = {name: val for name, val in d.execute(q)}
+    if c.get("SQ_BUSY_CYCLES"):
+        # one row per shader engine: 8 CUs = 32 SIMDs each; SQ_VALU_MFMA_BUSY_CYCLES sums over them
+        sq = {"counters_avg_per_shader_engine": c,
+              "mfma_busy_fraction": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0 / c["SQ_BUSY_CYCLES"],
+              "wave_time_split": {k: c.get(k, 0.0) / c["SQ_WAVE_CYCLES"] for k in
+                                  ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c.get("SQ_WAVE_CYCLES")}}
+res = {"isolated_kernel_trace": iso, "sq_counters": sq, "op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
        "algorithmic_bytes_per_launch": 4.0 * 16 * 65536 * (96 + 510),
        "kernels": out}
 with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
