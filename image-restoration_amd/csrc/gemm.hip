@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
 #pragma unroll
       for (int i = 0; i < WS; ++i) wr[i] = load_w(kt + 1, i);
     }
+    __builtin_amdgcn_sched_barrier(0);   // the next chunk's fetches stay ahead of this chunk's MFMAs
     const float* __restrict__ Ab = &As[buf][wm * WM + l31];
     const float* __restrict__ Bb = &Bs[buf][wn * WN + l31];
 #pragma unroll
@@ -511,6 +512,9 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
       const float* __restrict__ src = last ? ap_next : ap + (long)(2 * (s0 + XS_ABATCH)) * a.Mpad;
 #pragma unroll
       for (int i = 0; i < XS_ABATCH; ++i) a_nxt[i] = src[(long)(2 * i) * a.Mpad];
+      // keep the next batch's fetches in front of this batch's MFMAs: the scheduler otherwise sinks
+      // them to the end of the batch and their L2 latency is exposed at the top of the next one
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < XS_ABATCH; ++i) {
 #pragma unroll
