@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 // registers; the left / right neighbours come from the adjacent lanes (__shfl), only the lanes on
 // a tile edge touch memory for them.  One wave per task, no LDS, no barrier; every global access
 // is a 16-byte lane access on a contiguous row segment.
-template <int MODE>
+template <int MODE, int PX>
 __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __restrict__ x, long x_bs,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
@@ -328,23 +328,36 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
   const int ts = t % strips;
   const int c = t / strips;
   const int xq = lane & (LX - 1), yr = lane >> lx_log2;
-  const int px = (tx * LX + xq) * 4;
+  const int px = (tx * LX + xq) * PX;
   const int ys = (ts * RW + yr) * R;
   const long P = (long)H * W;
   const int Cout = MODE == 0 ? C : C / 2;
   const bool x_ok = px < W;
 
-  struct Row { float v[6]; };
+  struct Row { float v[PX + 2]; };
   auto load_row = [&](const float* __restrict__ plane, int yy) {
     Row r;
     const bool ok = x_ok && yy >= 0 && yy < H;
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) m[j] = 0.f;
     const float* __restrict__ p = plane + (long)yy * W + px;
-    if (ok) m = *reinterpret_cast<const float4*>(p);
-    float l = __shfl_up(m.w, 1), rr = __shfl_down(m.x, 1);
+    if (ok) {
+      if constexpr (PX == 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p);
+        m[0] = t4.x; m[1] = t4.y; m[2] = t4.z; m[3] = t4.w;
+      } else {
+        const float2 t2 = *reinterpret_cast<const float2*>(p);
+        m[0] = t2.x; m[1] = t2.y;
+      }
+    }
+    float l = __shfl_up(m[PX - 1], 1), rr = __shfl_down(m[0], 1);
     if (xq == 0) l = (ok && px > 0) ? p[-1] : 0.f;
-    if (xq == LX - 1 || px + 4 >= W) rr = (ok && px + 4 < W) ? p[4] : 0.f;
-    r.v[0] = l; r.v[1] = m.x; r.v[2] = m.y; r.v[3] = m.z; r.v[4] = m.w; r.v[5] = rr;
+    if (xq == LX - 1 || px + PX >= W) rr = (ok && px + PX < W) ? p[PX] : 0.f;
+    r.v[0] = l;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) r.v[1 + j] = m[j];
+    r.v[PX + 1] = rr;
     return r;
   };
 
@@ -377,16 +390,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
     const int oy = ys + i;
 #pragma unroll
     for (int g = 0; g < NP; ++g) rc[g] = load_row(plane[g], oy + 1);
-    float res[NP][4];
+    float res[NP][PX];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
       if (!conv[g]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) res[g][j] = rb[g].v[1 + j];
+        for (int j = 0; j < PX; ++j) res[g][j] = rb[g].v[1 + j];
         continue;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < PX; ++j) {
         float acc = bb[g];
         acc = fmaf(k[g][0], ra[g].v[j], acc);
         acc = fmaf(k[g][1], ra[g].v[j + 1], acc);
@@ -400,16 +413,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
         res[g][j] = acc;
       }
     }
-    float4 o;
-    if constexpr (MODE == 1 || MODE == 3) {
-      o = make_float4(gelu_erf_pw(res[0][0]) * res[NP - 1][0], gelu_erf_pw(res[0][1]) * res[NP - 1][1],
-                      gelu_erf_pw(res[0][2]) * res[NP - 1][2], gelu_erf_pw(res[0][3]) * res[NP - 1][3]);
-    } else if constexpr (MODE == 2) {
-      o = make_float4(res[0][0] * res[1][0], res[0][1] * res[1][1], res[0][2] * res[1][2], res[0][3] * res[1][3]);
-    } else {
-      o = make_float4(res[0][0], res[0][1], res[0][2], res[0][3]);
+    float o[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      if constexpr (MODE == 1 || MODE == 3) o[j] = gelu_erf_pw(res[0][j]) * res[NP - 1][j];
+      else if constexpr (MODE == 2) o[j] = res[0][j] * res[1][j];
+      else o[j] = res[0][j];
     }
-    if (x_ok && oy < H) *reinterpret_cast<float4*>(dst0 + (long)oy * W) = o;
+    if (x_ok && oy < H) {
+      if constexpr (PX == 4) *reinterpret_cast<float4*>(dst0 + (long)oy * W) = make_float4(o[0], o[1], o[2], o[3]);
+      else *reinterpret_cast<float2*>(dst0 + (long)oy * W) = make_float2(o[0], o[1]);
+    }
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
       ra[g] = rb[g];
@@ -431,19 +445,27 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
   const char* nm = wmod ? "dwconv3x3_partial" : gate == 1 ? "dwconv3x3_gate" : gate == 2 ? "dwconv3x3_mul"
                    : gate == 3 ? "dwconv3x3_gelu_mul" : "dwconv3x3";
   Scope sc(intern_label("%s C%d H%d W%d", nm, C, H, W), 18.0 * px * (gate >= 2 ? C / 2 : C), 4.0 * px * (C + Cout), s);
-  const bool vec = W % 4 == 0 && x.bs % 4 == 0 && y.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0 &&
-                   (reinterpret_cast<uintptr_t>(y.p) & 15) == 0;
-  if (vec) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(x.p) | reinterpret_cast<uintptr_t>(y.p);
+  const int PX = (W % 4 == 0 && x.bs % 4 == 0 && y.bs % 4 == 0 && (addr & 15) == 0)   ? 4
+                 : (W % 2 == 0 && x.bs % 2 == 0 && y.bs % 2 == 0 && (addr & 7) == 0) ? 2
+                                                                                     : 0;
+  if (PX) {
     int lx_log2 = 0;
-    while ((1 << lx_log2) < 64 && (4 << lx_log2) < W) ++lx_log2;    // lanes across a row: up to 64 x 4 px
+    while ((1 << lx_log2) < 64 && (PX << lx_log2) < W) ++lx_log2;   // lanes across a row: up to 64 x PX px
     const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
     const int R = std::max(1, std::min(8, H / RW));
-    const int tx = (W + 4 * LX - 1) / (4 * LX), strips = (H + RW * R - 1) / (RW * R);
+    const int tx = (W + PX * LX - 1) / (PX * LX), strips = (H + RW * R - 1) / (RW * R);
     const int n_tasks = tx * strips * Cout;
     const dim3 g2((unsigned)((n_tasks + 3) / 4), B);
-#define JIRF_DW_ROWS(M, WM, WC) \
-    hipLaunchKernelGGL(dwconv3x3_rows_kernel<M>, g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W, lx_log2, R, \
-                       tx, strips, n_tasks, WM, WC)
+#define JIRF_DW_ROWS(M, WM, WC)                                                                                      \
+  do {                                                                                                               \
+    if (PX == 4)                                                                                                     \
+      hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 4>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,     \
+                         lx_log2, R, tx, strips, n_tasks, WM, WC);                                                   \
+    else                                                                                                             \
+      hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 2>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,     \
+                         lx_log2, R, tx, strips, n_tasks, WM, WC);                                                   \
+  } while (0)
     if (gate == 1) JIRF_DW_ROWS(1, 0, 0);
     else if (gate == 2) JIRF_DW_ROWS(2, 0, 0);
     else if (gate == 3) JIRF_DW_ROWS(3, 0, 0);

@@ -101,7 +101,7 @@ def test_pixel_shuffle_bit_exact():
 
 @pytest.mark.parametrize("gate", [0, 1, 2])
 @pytest.mark.parametrize("B,C,H,W,bias", [(1, 254, 40, 56, False), (2, 30, 17, 70, True), (1, 144, 64, 64, False),
-                                          (1, 6, 5, 3, True)])
+                                          (1, 6, 5, 3, True), (1, 24, 82, 122, True)])
 def test_dwconv3x3(gate, B, C, H, W, bias):
     x, w = rnd(B, C, H, W), rnd(C, 1, 3, 3, scale=1 / 3)
     b = rnd(C) if bias else None
