@@ -264,3 +264,18 @@ def test_full_config_720p_batch_consistency():
     # B = 1 and B = 2 choose different split-K counts for the statistics, so sums differ in the
     # last bits; with the channel orders pinned the outputs agree far inside the parity bound
     assert max_abs(y1, y2[1:2]) < 1e-4
+
+
+def test_network_dual_pixel_task():
+    """dual_pixel_task=True (hint_arch.py:700-703): six input channels, the 1x1 skip from the patch
+    embedding, no global residual."""
+    cfg = dict(SMALL_CFG, dual_pixel_task=True, inp_channels=6, bias=True)
+    sd = make_hint_state(cfg, seed=8, gain=0.6)
+    x = np.concatenate([synthetic_images(1, 48, 64, seed=61, sigma=25), synthetic_images(1, 48, 64, seed=62)], axis=1)
+    y_ref, c_ref, names, perms, gaps = _oracle_run(sd, x, cfg)
+    net = _build(cfg, sd, "coupled")
+    net.native().plan(1, 48, 64, 1)
+    net.force_perms([p[None] for p in perms])
+    y = net(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert y.shape == (1, 3, 48, 64)
+    assert max_abs(y, y_ref) < TOL
