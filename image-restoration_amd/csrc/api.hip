@@ -253,7 +253,7 @@ int jirf_op_conv1x1(const float* x, const float* w_host, const float* bias_host,
     WeightPool pool;
     const PackedW w = pack_upload_1x1(pool, w_host, bias_host, Cout, Cin);
     GemmArgs g{};
-    g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt; g.bias = w.bias;
+    g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.bias = w.bias;
     g.x = tv(const_cast<float*>(x), (long)Cin * P);
     g.y = tv(y, (long)Cout * P);
     g.imgs_per_group = 1;
@@ -281,7 +281,7 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
     const TV xv = tv(const_cast<float*>(x), (long)Cin * P);
     if (!gemm_ln_inline(Cin)) launch_ln_stats(xv, mu, rstd, B, Cin, P, s);
     GemmArgs g{};
-    g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt;
+    g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane;
     g.x = xv; g.y = tv(y, (long)Cout * P); g.imgs_per_group = 1; g.epi = EP_STORE;
     g.mu = mu; g.rstd = rstd; g.lnw = ln_w; g.lnb = ln_kind == 1 ? ln_b : nullptr; g.ln_center = ln_kind == 1;
     launch_gemm(g, LD_LN, s);

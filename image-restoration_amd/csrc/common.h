@@ -81,6 +81,8 @@ struct GemmArgs {
   int Mpad;              // packed row length of Wt
   const float* wt;       // [Kpad][Mpad]
   long wt_bs;            // batch stride of wt (0: shared)
+  const uint16_t* wt3 = nullptr;  // optional: the same weights split into three bf16 planes (see pack_wt_split3)
+  long wt3_plane = 0;             // elements per plane
   const float* bias;     // [M] or null
   long bias_bs = 0;      // > 0: one bias vector per image, bias + b * bias_bs
   TV x;                  // input activation
@@ -110,6 +112,13 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, int loader, hipStream_t s);
 // true when the LD_LN loader computes the LayerNorm statistics itself (mu / rstd may be null)
 bool gemm_ln_inline(int K);
+// true when the split-bf16 GEMM variant is switched on (JIRF_GEMM_SPLIT_BF16=1): weights are then
+// also packed as three bf16 planes
+bool gemm_split_bf16_enabled();
+// w [M][K] fp32 -> three bf16 planes (hi, mid, lo with hi + mid + lo == w) laid out
+// [plane][Kp / 8][Mpad][8]: the 8 consecutive k of one MFMA operand are one 16-byte word per row.
+// Returns elements per plane.
+size_t pack_wt_split3(const float* w, int M, int K, int Mpad, std::vector<uint16_t>& out);
 // host-side packers (return Kpad; out is resized to Kpad * Mpad)
 int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad);
 int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad);

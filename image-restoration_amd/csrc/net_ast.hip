@@ -274,7 +274,7 @@ class AstNet final : public Net {
   void gemm(const PackedW& w, TV x, TV y, int B, int P, int epi, TV r, hipStream_t s) {
     GemmArgs g{};
     g.B = B; g.M = w.M; g.K = w.K; g.P = P; g.Mpad = w.Mpad;
-    g.wt = w.wt; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r; g.imgs_per_group = 1;
+    g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r; g.imgs_per_group = 1;
     launch_gemm(g, LD_PLAIN, s);
   }
   void conv(const PackedW& w, TV x, TV y, int B, int Hin, int Win, int ks, int stride, int pad, int epi, TV r,

@@ -238,7 +238,7 @@ class Astv2Net final : public Net {
             const float* lnw = nullptr, const float* lnb = nullptr) {
     GemmArgs g{};
     g.B = B; g.M = w.M; g.K = w.K; g.P = P; g.Mpad = w.Mpad;
-    g.wt = w.wt; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r; g.imgs_per_group = 1;
+    g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r; g.imgs_per_group = 1;
     if (loader == LD_LN) {
       g.mu = mu_; g.rstd = rstd_; g.lnw = lnw; g.lnb = lnb; g.ln_center = with_bias_ln_ ? 1 : 0;
     }

@@ -430,7 +430,7 @@ class HintNet final : public Net {
             int loader = LD_PLAIN, const LNW* ln = nullptr) {
     GemmArgs g{};
     g.B = B; g.M = w.M; g.K = w.K; g.P = P; g.Mpad = w.Mpad;
-    g.wt = w.wt; g.wt_bs = 0; g.bias = w.bias;
+    g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.wt_bs = 0; g.bias = w.bias;
     g.x = x; g.y = y; g.epi = epi; g.r = r;
     g.imgs_per_group = 1;
     if (loader == LD_LN) {

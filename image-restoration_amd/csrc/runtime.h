@@ -143,6 +143,8 @@ struct WeightPool {
 
 struct PackedW {
   const float* wt = nullptr;
+  const uint16_t* wt3 = nullptr;   // split-bf16 planes (only when that GEMM variant is enabled)
+  long wt3_plane = 0;
   const float* bias = nullptr;
   int M = 0, K = 0, Mpad = 0, Cin = 0;
 };

@@ -184,6 +184,13 @@ PackedW pack_upload_1x1(WeightPool& pool, const float* w, const float* bias, int
   out.wt = pool.upload(packed);
   out.bias = bias ? pool.upload(bias, M) : nullptr;
   out.M = M; out.K = K; out.Cin = K;
+  if (gemm_split_bf16_enabled() && K <= 128) {
+    std::vector<uint16_t> planes;
+    out.wt3_plane = (long)pack_wt_split3(w, M, K, out.Mpad, planes);
+    // uploaded through the float pool: two bf16 per float slot
+    planes.resize((planes.size() + 1) / 2 * 2, 0);
+    out.wt3 = reinterpret_cast<const uint16_t*>(pool.upload(reinterpret_cast<const float*>(planes.data()), planes.size() / 2));
+  }
   return out;
 }
 PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, int M, int Cin, int ks) {

@@ -1,0 +1,38 @@
+"""Child process of test_split_bf16_gpu.py: runs the 1x1 GEMM entry points once and prints, as one JSON
+line, their maximum absolute error against a float64 product.  Which GEMM kernel serves the calls is
+decided by JIRF_GEMM_SPLIT_BF16 in the environment the parent passes, read once per process."""
+import json
+import sys
+
+import numpy as np
+import torch
+
+from tests.gpu_util import call, dev, hptr, ptr, stream
+
+
+def main():
+    rng = np.random.default_rng(11)
+    out = {}
+    for (B, C, Cout, P) in [(2, 48, 254, 4096), (1, 96, 510, 4100), (1, 127, 48, 1000), (1, 128, 96, 777)]:
+        x = rng.standard_normal((B, C, P)).astype(np.float32) * 2 + 0.5
+        w = (rng.standard_normal((Cout, C)) * C ** -0.5).astype(np.float32)
+        res = rng.standard_normal((B, Cout, P)).astype(np.float32)
+        xd, rd = dev(x), dev(res)
+        y = torch.empty(B, Cout, P, device="cuda")
+        call("jirf_op_conv1x1", ptr(xd), hptr(w), None, ptr(rd), ptr(y), B, C, Cout, P, stream())
+        ref = np.einsum("oi,bip->bop", w.astype(np.float64), x.astype(np.float64)) + res
+        out[f"conv1x1_{C}_{Cout}_{P}"] = float(np.abs(y.cpu().numpy() - ref).max())
+        lw = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+        lb = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        x64 = x.astype(np.float64)
+        mu = x64.mean(1, keepdims=True)
+        n = (x64 - mu) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * lw[None, :, None] + lb[None, :, None]
+        ref = np.einsum("oi,bip->bop", w.astype(np.float64), n)
+        lwd, lbd = dev(lw), dev(lb)
+        call("jirf_op_ln_conv1x1", ptr(xd), ptr(lwd), ptr(lbd), 1, hptr(w), ptr(y), B, C, Cout, P, stream())
+        out[f"ln_conv1x1_{C}_{Cout}_{P}"] = float(np.abs(y.cpu().numpy() - ref).max())
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
