@@ -713,28 +713,34 @@ struct GroupAttnArgs {
   const float* gc_b[4];
   int n_chunks;             // column chunks of the modulation kernel
   int chunk_g[32], chunk_j0[32];
+  int sm_chunks, sm_rc;     // row chunks of the softmax kernel: sm_rc rows of group sm_g[] from row sm_r0[]
+  int sm_g[32], sm_r0[32];
   float* att_t;             // [B][Kpad][Mpad]
   float* att_nat;           // [B][C][C]
 };
 
 constexpr int GA_JC = 32;   // columns modulated per workgroup
 constexpr int GA_LD = 33;   // LDS row stride of the 32-column chunk images
+constexpr int GM_THREADS = 1024;   // modulation kernel: one 32-row output tile per wave, up to 16 at once
 
 __device__ __forceinline__ double sort_key(double v) { return v != v ? -INFINITY : v; }
 
 // ---- 3a. permutation, gather, scale, row softmax ---------------------------------------------------
-// One workgroup per (group, image).  Writes the softmax block in natural orientation; without a
-// cache that is already the final attention, so the transposed (GEMM weight) image is written too.
-// Either way the off-diagonal part of the rows this group owns in the transposed image is zeroed.
+// One workgroup per (group, chunk of sm_rc rows, image); every workgroup ranks the channels itself (a
+// few microseconds, cheaper than a launch of its own).  Writes the softmax rows in natural orientation;
+// without a cache that is already the final attention, so the transposed (GEMM weight) image is written
+// too.  Either way the off-diagonal part of the rows kr of the transposed image with kr - off inside
+// this chunk is zeroed (the last chunk of the last group also owns the padding rows).
 __global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ga_smem[];
-  const int gi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int gi = a.sm_g[blockIdx.x], r0 = a.sm_r0[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, c = a.gsz[gi], off = a.goff[gi];
+  const int rc = min(a.sm_rc, c - r0);
   const int g = b / a.ipg;
   const int ld = c + 1;
   double* key = reinterpret_cast<double*>(ga_smem);            // [C]
   int* perm = reinterpret_cast<int*>(key + C);                 // [C]
-  float* X = reinterpret_cast<float*>(perm + C + (C & 1));     // [c][ld]
+  float* X = reinterpret_cast<float*>(perm + C + (C & 1));     // [sm_rc][ld]
 
   // ---- channel permutation: descending similarity, ties by ascending channel ----
   if (a.forced_perm) {
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs 
     }
   }
   __syncthreads();
-  if (gi == 0 && b % a.ipg == 0)
+  if (blockIdx.x == 0 && b % a.ipg == 0)
     for (int i = tid; i < C; i += 256) a.perm_out[(long)g * C + i] = perm[i];
 
   // ---- gather + scale: X[r][s] = S[perm r][perm s] * rq[perm r] * rk[perm s] * T ----
@@ -761,15 +767,15 @@ __global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs 
   const float* __restrict__ S = a.s_qk + (long)b * C * C;
   // (unrolled: the gathers are dependent-latency bound otherwise, one global round trip per element)
 #pragma unroll 8
-  for (int e = tid; e < c * c; e += 256) {
+  for (int e = tid; e < rc * c; e += 256) {
     const int r = e / c, s = e - r * c;
-    const int ci = perm[off + r], cj = perm[off + s];
+    const int ci = perm[off + r0 + r], cj = perm[off + s];
     X[r * ld + s] = S[(long)ci * C + cj] * a.rq[(long)b * C + ci] * a.rk[(long)b * C + cj] * temp;
   }
   __syncthreads();
   {
     const int lane = tid & 63, wave = tid >> 6;
-    for (int r = wave; r < c; r += 4) {
+    for (int r = wave; r < rc; r += 4) {
       float m = -INFINITY;
       for (int s = lane; s < c; s += 64) m = fmaxf(m, X[r * ld + s]);
       for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -789,22 +795,24 @@ __global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs 
   const int kpad = ((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD;
   float* __restrict__ att_t = a.att_t + (long)b * kpad * a.Mpad;
   float* __restrict__ att_nat = a.att_nat + (long)b * C * C;
-  for (int e = tid; e < c * c; e += 256) {
+  for (int e = tid; e < rc * c; e += 256) {
     const int r = e / c, s = e - r * c;
-    att_nat[(long)(off + r) * C + off + s] = X[r * ld + s];
+    att_nat[(long)(off + r0 + r) * C + off + s] = X[r * ld + s];
   }
-  // rows [off, off + c) of the transposed image belong to this group (the last group also owns
-  // the padding rows)
-  const int row_end = gi == 3 ? kpad : off + c;
-  const bool final_here = a.pooled == nullptr;
-  for (int e = tid; e < (row_end - off) * a.Mpad; e += 256) {
-    const int kr = off + e / a.Mpad, m = e % a.Mpad;
+  // zero the part of rows [off + r0, off + r0 + rc) of the transposed image outside the diagonal block
+  const bool last = gi == 3 && r0 + rc == c;
+  const int row_lo = off + r0, row_hi = last ? kpad : off + r0 + rc;
+  for (int e = tid; e < (row_hi - row_lo) * a.Mpad; e += 256) {
+    const int kr = row_lo + e / a.Mpad, m = e % a.Mpad;
     const bool inside = kr < off + c && m >= off && m < off + c;
-    if (!inside)
-      att_t[(long)kr * a.Mpad + m] = 0.f;
-    else if (final_here)
-      att_t[(long)kr * a.Mpad + m] = X[(m - off) * ld + (kr - off)];
+    if (!inside) att_t[(long)kr * a.Mpad + m] = 0.f;
   }
+  // softmax row r is column off + r0 + r of the transposed image
+  if (a.pooled == nullptr)
+    for (int e = tid; e < rc * c; e += 256) {
+      const int s = e / rc, r = e - s * rc;
+      att_t[(long)(off + s) * a.Mpad + off + r0 + r] = X[r * ld + s];
+    }
 }
 
 // ---- 3b. the cache pooled to every group's c x c (Inter_CacheModulation.align) ---------------------
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(256) void cache_pool_groups_kernel(const GroupAttnA
 //   Z = Ww (Pg + X) + bw ;  Y = X * Z[:c] + Z[c:] ;  att = Y * gelu(Wg Y + bg) + X
 // Both products run on fp32 MFMA (32x32x2): A = K-major packed weights straight from global
 // (128-byte rows), B = the chunk image in LDS.
-__global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs a) {
+__global__ __launch_bounds__(GM_THREADS) void group_modulate_kernel(const GroupAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
   const int gi = a.chunk_g[blockIdx.x], j0 = a.chunk_j0[blockIdx.x];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -849,7 +857,7 @@ __global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs
   const float* __restrict__ pg = a.pooled_g + (long)g * a.psum + a.poff[gi];
 
 #pragma unroll 4
-  for (int e = tid; e < c * GA_JC; e += 256) {
+  for (int e = tid; e < c * GA_JC; e += GM_THREADS) {
     const int r = e >> 5, jj = e & 31;
     float x = 0.f, xp = 0.f;
     if (jj < nj) {
@@ -866,7 +874,7 @@ __global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs
   {
     const float* __restrict__ Wt = a.cw_wt[gi];
     const float* __restrict__ bw = a.cw_b[gi];
-    for (int mt = wave; mt < mp2 / 32; mt += 4) {
+    for (int mt = wave; mt < mp2 / 32; mt += GM_THREADS / 64) {
       f32x16_t acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs
     }
   }
   __syncthreads();
-  for (int e = tid; e < c * GA_JC; e += 256) {
+  for (int e = tid; e < c * GA_JC; e += GM_THREADS) {
     const int o = e >> 5, jj = e & 31;
     Ys[o * GA_LD + jj] = jj < nj ? Xs[o * GA_LD + jj] * Zs[o * GA_LD + jj] + Zs[(c + o) * GA_LD + jj] : 0.f;
   }
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(256) void group_modulate_kernel(const GroupAttnArgs
     const float* __restrict__ bg = a.gc_b[gi];
     const int kpad = ((C + GEMM_KPAD - 1) / GEMM_KPAD) * GEMM_KPAD;
     float* __restrict__ att_t = a.att_t + (long)b * kpad * a.Mpad;
-    for (int mt = wave; mt < mp1 / 32; mt += 4) {
+    for (int mt = wave; mt < mp1 / 32; mt += GM_THREADS / 64) {
       f32x16_t acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1117,10 +1125,21 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
       }
     }
     ga.psum = psum; ga.n_chunks = nch;
+    // softmax row chunks: 16 rows each unless that needs more than 32 workgroups per image
+    int rcs = 16;
+    auto sm_count = [&](int rc) { int n = 0; for (int i = 0; i < 4; ++i) n += (sh.gsz[i] + rc - 1) / rc; return n; };
+    while (sm_count(rcs) > 32) rcs *= 2;
+    ga.sm_rc = rcs; ga.sm_chunks = 0;
+    for (int i = 0; i < 4; ++i)
+      for (int r0 = 0; r0 < sh.gsz[i]; r0 += rcs) {
+        ga.sm_g[ga.sm_chunks] = i;
+        ga.sm_r0[ga.sm_chunks] = r0;
+        ++ga.sm_chunks;
+      }
     ga.sim = sim; ga.forced_perm = forced_perm; ga.perm_out = perm_out;
     ga.s_qk = sc.s_qk; ga.rq = sc.rq; ga.rk = sc.rk; ga.temperature = w.temperature;
     ga.pooled = pooled; ga.pooled_g = sc.pooled_g; ga.att_t = sc.att_t; ga.att_nat = sc.att_nat;
-    const size_t smem_a = (size_t)C * 8 + ((size_t)C + (C & 1)) * 4 + (size_t)cmax * (cmax + 1) * 4;
+    const size_t smem_a = (size_t)C * 8 + ((size_t)C + (C & 1)) * 4 + (size_t)std::min(rcs, cmax) * (cmax + 1) * 4;
     const size_t smem_c = ((size_t)3 * cmax + (2 * cmax + 31) / 32 * 32) * GA_LD * 4;
     JIRF_REQUIRE(smem_a <= 160 * 1024 && smem_c <= 160 * 1024, JIRF_EINVAL,
                  "hint attention: channel group of %d does not fit LDS (%zu / %zu bytes)", cmax, smem_a, smem_c);
@@ -1134,7 +1153,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     }
     {
       Scope scope(intern_label("hint_group_softmax C%d", C), 0.0, 12.0 * B * (double)C * C, s);
-      hipLaunchKernelGGL(group_softmax_kernel, dim3(4, B), dim3(256), smem_a, s, ga);
+      hipLaunchKernelGGL(group_softmax_kernel, dim3(ga.sm_chunks, B), dim3(256), smem_a, s, ga);
       JIRF_HIP_CHECK(hipGetLastError());
     }
     if (pooled) {
@@ -1146,7 +1165,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
       double fl = 0.0;
       for (int i = 0; i < 4; ++i) fl += 6.0 * sh.gsz[i] * (double)sh.gsz[i] * sh.gsz[i];
       Scope scope(intern_label("hint_group_modulate C%d", C), fl * B, 16.0 * B * (double)psum, s);
-      hipLaunchKernelGGL(group_modulate_kernel, dim3(nch, B), dim3(256), smem_c, s, ga);
+      hipLaunchKernelGGL(group_modulate_kernel, dim3(nch, B), dim3(GM_THREADS), smem_c, s, ga);
       JIRF_HIP_CHECK(hipGetLastError());
     }
   }
