@@ -158,6 +158,9 @@ void launch_reflect_pad(const float* x, float* y, int B, int C, int H, int W, in
 void launch_split_tiles(const float* x, float* tiles, const TileGrid& g, int B, int C, int H, int W, hipStream_t s);
 void launch_merge_tiles(const float* tiles, float* out, const TileGrid& g, int B, int C, int H, int W, hipStream_t s);
 void launch_crop_clamp(const float* x, void* y, int B, int C, int H, int W, int h, int w, bool to_u8, hipStream_t s);
+size_t psnr_work_doubles();
+void launch_psnr_stats(const float* a, const float* b, int C, int H, int W, int border, int quantise, int y_channel,
+                       int blue_plane, double* work, hipStream_t s);
 
 // Dense 3x3 (stride 1, zero pad 1) with at most 4 output channels, on the vector ALUs; weights in
 // the GEMM's K-major packing wt[(tap * Cin + c) * Mpad + o].  Returns false (nothing launched)

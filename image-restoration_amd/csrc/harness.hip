@@ -161,4 +161,98 @@ void launch_crop_clamp(const float* x, void* y, int B, int C, int H, int W, int 
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
+// ---- PSNR statistics (basicsr/metrics/psnr_ssim.py:11-69 of the reference) ------------------------------
+// Two planar [C][H][W] images -> sum of squared differences (fp64), maximum of the first image's
+// values and the number of values compared, over the window that crop_border leaves.  quantise != 0
+// first turns both into the uint8 image tensor2img makes (img_util.py:136-166: clamp to [0, 1], times
+// 255 in float32, round half to even); y_channel != 0 then reduces three colour planes to the BT.601
+// luma of to_y_channel (metric_util.py:34-47 with matlab_functions.py:268-282): planes scaled to [0, 1]
+// in float32, the weighted sum and + 16 in float64, / 255 in float64, stored as float32, times 255 in
+// float32.  blue_plane names the plane weighted 24.966 (2 for RGB planes that the reference's
+// rgb2bgr swap has turned into BGR, 0 if it was left off and red is taken for blue).
+// Deterministic: fixed grid, per-workgroup partials, then one workgroup folds them in index order.
+constexpr int PSNR_BLOCKS = 256;
+
+__device__ __forceinline__ float quantise_u8(float v) { return rintf(fminf(fmaxf(v, 0.f), 1.f) * 255.0f); }
+
+__global__ __launch_bounds__(256) void psnr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           int C, int H, int W, int border, int quantise,
+                                                           int y_channel, int blue_plane, double* __restrict__ work) {
+  const int h = H - 2 * border, w = W - 2 * border;
+  const long npix = (long)h * w, plane = (long)H * W;
+  double sse = 0.0;
+  float mx = -INFINITY;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)PSNR_BLOCKS * 256) {
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const long at = (long)(y + border) * W + x + border;
+    if (y_channel) {
+      double ya = 16.0, yb = 16.0;
+      const double wgt[3] = {24.966, 128.553, 65.481};
+      for (int k = 0; k < 3; ++k) {                   // k = 0: blue, 1: green, 2: red
+        const int pl = k == 1 ? 1 : (k == 0 ? blue_plane : 2 - blue_plane);
+        float va = a[pl * plane + at], vb = b[pl * plane + at];
+        if (quantise) { va = quantise_u8(va); vb = quantise_u8(vb); }
+        ya += (double)(va / 255.0f) * wgt[k];
+        yb += (double)(vb / 255.0f) * wgt[k];
+      }
+      const float fa = (float)(ya / 255.0) * 255.0f, fb = (float)(yb / 255.0) * 255.0f;
+      const double d = (double)fa - (double)fb;
+      sse += d * d;
+      mx = fmaxf(mx, fa);
+    } else {
+      for (int c = 0; c < C; ++c) {
+        float va = a[c * plane + at], vb = b[c * plane + at];
+        if (quantise) { va = quantise_u8(va); vb = quantise_u8(vb); }
+        const double d = (double)va - (double)vb;
+        sse += d * d;
+        mx = fmaxf(mx, va);
+      }
+    }
+  }
+  __shared__ double s_sse[256];
+  __shared__ float s_mx[256];
+  s_sse[threadIdx.x] = sse;
+  s_mx[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s_sse[threadIdx.x] += s_sse[threadIdx.x + o];
+      s_mx[threadIdx.x] = fmaxf(s_mx[threadIdx.x], s_mx[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    work[4 + 2 * blockIdx.x] = s_sse[0];
+    work[5 + 2 * blockIdx.x] = (double)s_mx[0];
+  }
+}
+
+__global__ __launch_bounds__(64) void psnr_final_kernel(double* __restrict__ work, double count) {
+  if (threadIdx.x != 0) return;
+  double sse = 0.0, mx = -INFINITY;
+  for (int i = 0; i < PSNR_BLOCKS; ++i) {
+    sse += work[4 + 2 * i];
+    mx = fmax(mx, work[5 + 2 * i]);
+  }
+  work[0] = sse;
+  work[1] = mx;
+  work[2] = count;
+}
+
+size_t psnr_work_doubles() { return 4 + 2 * (size_t)PSNR_BLOCKS; }
+
+void launch_psnr_stats(const float* a, const float* b, int C, int H, int W, int border, int quantise, int y_channel,
+                       int blue_plane, double* work, hipStream_t s) {
+  JIRF_REQUIRE(border >= 0 && 2 * border < H && 2 * border < W, JIRF_EINVAL, "psnr: crop_border %d leaves nothing of %dx%d",
+               border, H, W);
+  JIRF_REQUIRE(!y_channel || C == 3, JIRF_EINVAL, "psnr: the Y channel needs 3 colour planes, got %d", C);
+  JIRF_REQUIRE(blue_plane == 0 || blue_plane == 2, JIRF_EINVAL, "psnr: blue_plane must be 0 or 2");
+  const double count = (double)(H - 2 * border) * (W - 2 * border) * (y_channel ? 1 : C);
+  hipLaunchKernelGGL(psnr_partial_kernel, dim3(PSNR_BLOCKS), dim3(256), 0, s, a, b, C, H, W, border, quantise, y_channel,
+                     blue_plane, work);
+  JIRF_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(psnr_final_kernel, dim3(1), dim3(64), 0, s, work, count);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace jirf

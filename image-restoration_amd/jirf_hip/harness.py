@@ -34,17 +34,23 @@ def pad_amounts(h: int, w: int, factor: int = 8) -> Tuple[int, int]:
     return (H - h if h % factor != 0 else 0), (W - w if w % factor != 0 else 0)
 
 
-def pad_to_factor(x: torch.Tensor, factor: int = 8) -> torch.Tensor:
-    """test_rain100L.py:147-152: reflect-pad bottom / right to a multiple of `factor`."""
+def reflect_pad(x: torch.Tensor, pad_bottom: int, pad_right: int) -> torch.Tensor:
+    """nn.pad(x, (0, pad_right, 0, pad_bottom), "reflect") (test_rain100L.py:152;
+    basicsr/models/image_restoration_model.py:286)."""
     x = _dev(x)
     b, c, h, w = x.shape
-    padh, padw = pad_amounts(h, w, factor)
-    if padh == 0 and padw == 0:
+    if pad_bottom == 0 and pad_right == 0:
         return x
-    y = torch.empty((b, c, h + padh, w + padw), dtype=torch.float32, device=x.device)
+    y = torch.empty((b, c, h + pad_bottom, w + pad_right), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib().jirf_op_reflect_pad(_ptr(x), _ptr(y), b, c, h, w, padh, padw, _stream(x)))
+        check(lib().jirf_op_reflect_pad(_ptr(x), _ptr(y), b, c, h, w, pad_bottom, pad_right, _stream(x)))
     return y
+
+
+def pad_to_factor(x: torch.Tensor, factor: int = 8) -> torch.Tensor:
+    """test_rain100L.py:147-152: reflect-pad bottom / right to a multiple of `factor`."""
+    _, _, h, w = x.shape
+    return reflect_pad(x, *pad_amounts(h, w, factor))
 
 
 def tile_starts(length: int, crop_size: int, overlap_size: int) -> List[int]:

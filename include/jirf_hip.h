@@ -186,6 +186,18 @@ int jirf_op_crop_clamp(const float* x, float* y, int B, int C, int H, int W, int
 /* The same followed by .permute(0,2,3,1) and skimage img_as_ubyte (test_rain100L.py:176-190):
  * y [B,h,w,C] uint8 = rint(clamp(x, 0, 1) * 255) (float32 product, round half to even). */
 int jirf_op_crop_clamp_u8(const float* x, uint8_t* y, int B, int C, int H, int W, int h, int w, void* stream);
+/* calculate_psnr (basicsr/metrics/psnr_ssim.py:11-69) on two planar [C,H,W] device images, as its three
+ * ingredients: after the call completes on `stream`, work[0] = sum of squared differences (float64),
+ * work[1] = maximum of the first image (psnr_ssim.py:68 picks the peak value from it), work[2] = number of
+ * values compared.  crop_border as :57-59.  quantise != 0 first makes the uint8 images of tensor2img
+ * (basicsr/utils/img_util.py:136-166: clamp [0,1], * 255, round half to even) - the `use_image: true`
+ * path of image_restoration_model.py:389-394.  y_channel != 0 (needs C == 3 and values in [0,255], i.e.
+ * quantise or 8-bit input) compares the BT.601 luma of to_y_channel (basicsr/metrics/metric_util.py:34-47);
+ * blue_plane = 2 when planes are R,G,B and the caller had rgb2bgr on, 0 when it was off.
+ * `work` is DEVICE memory of jirf_op_psnr_work_doubles() float64 values, owned by the caller. */
+int jirf_op_psnr_work_doubles(void);
+int jirf_op_psnr_stats(const float* a, const float* b, int C, int H, int W, int crop_border, int quantise, int y_channel,
+                       int blue_plane, double* work, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,121 @@
+"""The validation path of the reference's model class on the GPU: calculate_psnr, tensor2img, pad_test and
+the metric loop (basicsr/models/image_restoration_model.py:278-411), against the numpy restatement in
+oracle/metrics_oracle.py and the torch-CPU oracle of the network."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import astv2_oracle, metrics_oracle as mo
+from tests.make_golden import ASTV2_SMALL
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(5)
+
+
+def _pair(c, h, w, lo=-0.1, hi=1.1):
+    a = RNG.uniform(lo, hi, (c, h, w)).astype(np.float32)
+    b = (a + RNG.normal(0, 0.05, a.shape)).astype(np.float32)
+    return a, b
+
+
+@pytest.mark.parametrize("c,h,w,border", [(3, 37, 52, 0), (3, 64, 64, 4), (1, 19, 23, 2)])
+def test_psnr_float_tensors(c, h, w, border):
+    from basicsr.metrics import calculate_psnr
+    a, b = _pair(c, h, w)
+    want = mo.calculate_psnr(a.transpose(1, 2, 0), b.transpose(1, 2, 0), border)
+    got = calculate_psnr(torch.from_numpy(a).cuda()[None], torch.from_numpy(b).cuda()[None], border)
+    assert abs(got - want) < 1e-9
+    # peak-value rule (psnr_ssim.py:68): values within [0, 1] are scored against 1.0
+    a2, b2 = np.clip(a, 0, 1), np.clip(b, 0, 1)
+    want = mo.calculate_psnr(a2.transpose(1, 2, 0), b2.transpose(1, 2, 0), border)
+    got = calculate_psnr(a2, b2, border, input_order="CHW")
+    assert abs(got - want) < 1e-9 and want < 60
+    assert calculate_psnr(a2, a2, 0, input_order="CHW") == float("inf")
+
+
+@pytest.mark.parametrize("y", [False, True])
+@pytest.mark.parametrize("rgb2bgr", [True, False])
+def test_psnr_uint8_images_and_y_channel(y, rgb2bgr):
+    from basicsr.metrics import calculate_psnr
+    from basicsr.metrics.psnr_ssim import psnr_from_stats, psnr_stats
+    from basicsr.utils import tensor2img
+    a, b = _pair(3, 45, 61)
+    ia, ib = mo.tensor2img(a, rgb2bgr), mo.tensor2img(b, rgb2bgr)
+    want = mo.calculate_psnr(ia, ib, 3, test_y_channel=y)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    ga = tensor2img(ta[None], rgb2bgr=rgb2bgr)
+    assert ga.dtype == np.uint8 and np.array_equal(ga, ia)                 # bit-exact 8-bit image
+    got = calculate_psnr(ga, tensor2img([tb], rgb2bgr=rgb2bgr), 3, test_y_channel=y)
+    assert abs(got - want) < 1e-6
+    fused = psnr_from_stats(*psnr_stats(ta, tb, 3, True, y, 2 if rgb2bgr else 0))
+    assert abs(fused - want) < 1e-6
+
+
+def test_psnr_argument_errors():
+    from basicsr.metrics import calculate_psnr, calculate_ssim
+    a = np.zeros((8, 8, 3), np.float32)
+    with pytest.raises(AssertionError):
+        calculate_psnr(a, np.zeros((8, 9, 3), np.float32), 0)
+    with pytest.raises(ValueError):
+        calculate_psnr(a, a, 0, input_order="WHC")
+    with pytest.raises(Exception, match="crop_border"):
+        calculate_psnr(a, a, 4)
+    with pytest.raises(NotImplementedError):
+        calculate_ssim(a, a, 0)
+
+
+def test_validation_loop_matches_oracle(tmp_path):
+    """create_model -> load .jth -> pad_test(window 8) -> PSNR, on images whose sides are not multiples
+    of 8, against the oracle network + numpy metrics; then the same through `python -m basicsr.test`."""
+    from PIL import Image
+    from basicsr.models import create_model
+    from basicsr import test as test_entry
+    from jirf_hip import checkpoint, synthetic
+    cfg = dict(ASTV2_SMALL)
+    sd = synthetic.make_state("ASTv2", cfg, seed=4)
+    ck = tmp_path / "net_g_latest.jth"
+    checkpoint.save({"params": sd}, str(ck))
+    (tmp_path / "gt").mkdir()
+    (tmp_path / "lq").mkdir()
+    pairs = []
+    for i, (h, w) in enumerate([(37, 52), (40, 48)]):
+        gt = RNG.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        lq = np.clip(gt.astype(np.int32) + RNG.integers(-30, 31, gt.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(gt).save(tmp_path / "gt" / f"{i}.png")
+        Image.fromarray(lq).save(tmp_path / "lq" / f"{i}.png")
+        pairs.append((lq, gt))
+    state = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    want = {"img": [], "float": []}
+    for lq, gt in pairs:
+        x = torch.from_numpy(lq.astype(np.float32).transpose(2, 0, 1) / 255.0)[None]
+        g = gt.astype(np.float32).transpose(2, 0, 1) / 255.0
+        h, w = x.shape[2:]
+        ph, pw = (8 - h % 8) % 8, (8 - w % 8) % 8
+        xp = torch.nn.functional.pad(x, (0, pw, 0, ph), mode="reflect")
+        out = astv2_oracle.astv2_forward(state, xp, cfg)[0, :, :h, :w].numpy()
+        want["img"].append(mo.calculate_psnr(mo.tensor2img(out), mo.tensor2img(g), 0))
+        want["float"].append(mo.calculate_psnr(out.transpose(1, 2, 0), g.transpose(1, 2, 0), 0))
+    opt = {
+        "name": "t", "model_type": "ImageCleanModel", "scale": 1,
+        "datasets": {"test_1": {"name": "pairs", "type": "Dataset_PairedImage", "dataroot_gt": str(tmp_path / "gt"),
+                                "dataroot_lq": str(tmp_path / "lq"), "io_backend": {"type": "disk"}}},
+        "network_g": dict(cfg, type="ASTv2"),
+        "path": {"pretrain_network_g": str(ck), "strict_load_g": True, "param_key": "params_ema",
+                 "visualization": str(tmp_path / "vis")},
+        "val": {"window_size": 8, "save_img": True, "rgb2bgr": True, "use_image": True,
+                "metrics": {"psnr": {"type": "calculate_psnr", "crop_border": 0, "test_y_channel": False}}},
+    }
+    import yaml
+    yml = tmp_path / "opt.yml"
+    yml.write_text(yaml.safe_dump(opt))
+    res = test_entry.main(["-opt", str(yml)])
+    assert abs(res["pairs"]["psnr"] - np.mean(want["img"])) < 0.01          # |dPSNR| <= 0.01 dB
+    saved = np.asarray(Image.open(tmp_path / "vis" / "pairs" / "0.png"))
+    assert saved.shape == (37, 52, 3)
+    # float-tensor metrics (use_image: false, what most option files set)
+    opt["is_train"] = False
+    model = create_model(opt)
+    from basicsr.data import create_dataloader, create_dataset
+    loader = create_dataloader(create_dataset(opt["datasets"]["test_1"]))
+    got = model.validation(loader, "t", None, save_img=False, rgb2bgr=True, use_image=False)
+    assert abs(got - np.mean(want["float"])) < 0.01
