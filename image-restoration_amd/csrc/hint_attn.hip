@@ -275,6 +275,10 @@ __global__ __launch_bounds__(256, 2) void chan_stats96_kernel(const StatsArgs a)
   const bool diag = ti == tj;
   const bool gram_on = DO_GRAM && ti <= tj;
   if (!DO_QK && !gram_on) return;
+  // fixed heads of head_ch channels (head_ch divides the tile edge): only the diagonal tile pairs
+  // hold head blocks, and of their quadrants only those that meet one
+  const int hch = DO_GRAM ? 0 : a.head_ch;
+  if (hch > 0 && !diag) return;
   const int c_begin = sp * a.chunks_per_split;
   const int c_end = min(c_begin + a.chunks_per_split, (P + ST_CH - 1) / ST_CH);
 
@@ -325,7 +329,13 @@ __global__ __launch_bounds__(256, 2) void chan_stats96_kernel(const StatsArgs a)
 #pragma unroll
     for (int it = 0; it < 9; ++it) {
       const int qi = it / 3, qj = it % 3;
-      if (qi < nr && qj < nc) {
+      bool needed = qi < nr && qj < nc;
+      if (hch > 0 && needed) {   // heads met by the quadrant's rows and by its columns must overlap
+        const int r_lo = (qi * 32) / hch, r_hi = min(qi * 32 + 31, SQ_T - 1) / hch;
+        const int c_lo = (qj * 32) / hch, c_hi = min(qj * 32 + 31, SQ_T - 1) / hch;
+        needed = max(r_lo, c_lo) <= min(r_hi, c_hi);
+      }
+      if (needed) {
         const int w = least();
         if (w == wave) push(scode, qi * 4 + qj);
         give(w, 1);
@@ -1280,7 +1290,12 @@ size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, Head
   return off;
 }
 
-int head_attn_splits(int B, int C, int P) { return stats_splits((C + ST_T - 1) / ST_T, B, P); }
+// heads whose size divides the 96-channel super tile use that kernel (diagonal tile pairs only)
+static bool head_uses_sq96(int ch) { return SQ_T % ch == 0; }
+// upper bound over both statistics kernels (sizes the partial-sum scratch)
+int head_attn_splits(int B, int C, int P) {
+  return std::max(stats_splits((C + ST_T - 1) / ST_T, B, P), stats_splits((C + SQ_T - 1) / SQ_T, B, P));
+}
 
 void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const float* temperature,
                            const float* ca_w, const float* ca_b, const HeadAttnScratch& sc,
@@ -1289,8 +1304,9 @@ void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const flo
   const int ch = C / heads;
   const size_t smem = (size_t)4 * ch * (ch + 1) * 4;
   JIRF_REQUIRE(smem <= 160 * 1024, JIRF_EINVAL, "head attention: %d channels per head do not fit LDS", ch);
-  const int splits = head_attn_splits(B, C, P);
-  const int tiles = (C + ST_T - 1) / ST_T;
+  const bool sq96 = head_uses_sq96(ch);
+  const int tiles = sq96 ? (C + SQ_T - 1) / SQ_T : (C + ST_T - 1) / ST_T;
+  const int splits = stats_splits(tiles, B, P);
   const int chunks = (P + ST_CH - 1) / ST_CH;
   StatsArgs st{};
   st.q = q.p; st.q_bs = q.bs; st.k = k.p; st.k_bs = k.bs;
@@ -1301,7 +1317,8 @@ void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const flo
   {
     Scope scope(intern_label("head_chan_stats C%d P%d S%d", C, P, splits), 2.0 * C * (double)ch * P * B,
                 8.0 * B * (double)C * P, s);
-    launch_chan_stats<true, false>(st, B, s);
+    if (sq96) launch_chan_stats96<true, false>(st, B, s);
+    else launch_chan_stats<true, false>(st, B, s);
   }
   {
     Scope scope("head_reduce_rows", 1.0 * C * (double)C * splits * B, 4.0 * C * (double)C * splits * B, s);
