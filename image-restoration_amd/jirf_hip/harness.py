@@ -53,6 +53,23 @@ def pad_to_factor(x: torch.Tensor, factor: int = 8) -> torch.Tensor:
     return reflect_pad(x, *pad_amounts(h, w, factor))
 
 
+def square_side(h: int, w: int, multiple: int = 128) -> int:
+    """Side of the smallest square with side % multiple == 0 that holds an h x w image."""
+    return -(-max(h, w) // multiple) * multiple
+
+
+def pad_to_square(x: torch.Tensor, multiple: int = 128) -> torch.Tensor:
+    """Reflect-pad bottom / right to the enclosing square (side % multiple == 0).  The reference's AST
+    reshapes its tokens to sqrt(L) x sqrt(L) with windows of 8 at four scales (ast_arch.py:573, 592, 668,
+    770), so it only takes such squares; its scripts never feed it anything else.  Padding other images up
+    to one is this package's choice, not behaviour of the reference."""
+    _, _, h, w = x.shape
+    side = square_side(h, w, multiple)
+    if side - h >= h or side - w >= w:
+        raise ValueError(f"reflect padding {h}x{w} to {side}x{side} needs more rows or columns than the image has")
+    return reflect_pad(x, side - h, side - w)
+
+
 def tile_starts(length: int, crop_size: int, overlap_size: int) -> List[int]:
     """test_rain100L.py:33-36."""
     if crop_size <= overlap_size:
@@ -132,13 +149,14 @@ def to_uint8_image(restored: torch.Tensor, h: int, w: int) -> torch.Tensor:
 
 
 def restore_image(net, img: torch.Tensor, factor: int = 8, crop_size: int = None, overlap_size: int = None,
-                  tile_batch: int = 16) -> torch.Tensor:
+                  tile_batch: int = 16, square_multiple: int = None) -> torch.Tensor:
     """One image through a test script's loop body (test_rain100L.py:147-190): pad, restore (whole
     image, or `crop_size` tiles with `overlap_size` overlap as the FPro / GoPro branches do),
-    unpad, clamp.  img: [1,3,h,w] float32 on the GPU; returns [1,3,h,w]."""
+    unpad, clamp.  img: [B,3,h,w] float32 on the GPU; returns [B,3,h,w].  With `square_multiple` the image
+    is padded to the enclosing square instead (`pad_to_square`, for AST)."""
     x = _dev(img)
     h, w = x.shape[2], x.shape[3]
-    xp = pad_to_factor(x, factor)
+    xp = pad_to_square(x, square_multiple) if square_multiple else pad_to_factor(x, factor)
     if crop_size is None:
         restored = net(xp)
     else:

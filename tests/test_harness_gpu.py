@@ -63,3 +63,28 @@ def test_restore_image_tiled_equals_manual_pipeline():
     outs = [net(torch.from_numpy(np.ascontiguousarray(t)).cuda()).cpu().numpy() for t in split]
     want = ho.crop_clamp(ho.mergeimage(outs, starts, 48, xp.shape), 83, 117)
     assert np.array_equal(got, want)
+
+
+def test_ast_enclosing_square_policy():
+    """An image AST does not take (not square, side not a multiple of 128) is reflect-padded to the enclosing
+    128-multiple square, restored and cropped; equals the oracle network on the same padded image."""
+    from basicsr.models.archs import define_network
+    from jirf_hip import harness as hh
+    from jirf_hip.synthetic import make_state, synthetic_images
+    from oracle import ast_oracle
+    from tests.make_golden import AST_SHALLOW
+    cfg = dict(AST_SHALLOW)
+    sd = make_state("AST", cfg, seed=6)
+    net = define_network(dict(cfg, type="AST"))
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synthetic_images(1, 100, 120, seed=8, sigma=15)
+    assert hh.square_side(100, 120) == 128 and hh.square_side(321, 481) == 512 and hh.square_side(256, 256) == 256
+    got = hh.restore_image(net, torch.from_numpy(x).cuda(), square_multiple=128).cpu().numpy()
+    xp = np.pad(x, ((0, 0), (0, 0), (0, 28), (0, 8)), mode="reflect")
+    state = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    want = np.clip(ast_oracle.ast_forward(state, torch.from_numpy(xp), cfg).numpy()[:, :, :100, :120], 0, 1)
+    assert got.shape == (1, 3, 100, 120)
+    assert np.abs(got - want).max() < 1e-3
+    with pytest.raises(ValueError, match="reflect padding"):
+        hh.pad_to_square(torch.zeros(1, 3, 40, 200, device="cuda"))
