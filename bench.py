@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="image width (default: --size)")
     ap.add_argument("--arch", default="HINT", choices=["HINT", "ASTv2", "AST", "FPro"],
                     help="network; the headline workload is HINT (the other two are parity configs)")
+    ap.add_argument("--crop-size", type=int, default=0, help="restore in tiles of this size (the tiled branch of the test scripts)")
+    ap.add_argument("--overlap-size", type=int, default=0, help="overlap of those tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", default=None, help="write the per-shape kernel table to this file")
@@ -126,13 +128,15 @@ def main():
     # takes squares with side % 128 == 0: other images are padded to the enclosing one (a choice of this
     # package; MP/s counts the unpadded pixels).
     need = {"HINT": 8, "ASTv2": 8, "FPro": 32, "AST": 128}[args.arch]
-    script_path = Hh % need != 0 or Ww % need != 0 or (args.arch == "AST" and Hh != Ww)
+    script_path = Hh % need != 0 or Ww % need != 0 or (args.arch == "AST" and Hh != Ww) or args.crop_size > 0
     if script_path:
         from jirf_hip import harness
 
     def step():
         if args.arch == "HINT":
             net.qv_cache = None      # every image is a cold-start call
+        if args.crop_size:      # tiles are independent units: pad to 8 like the scripts, split, restore, mean-blend
+            return harness.restore_image(net, x, factor=8, crop_size=args.crop_size, overlap_size=args.overlap_size)
         if script_path:
             return harness.restore_image(net, x, factor=need, square_multiple=128 if args.arch == "AST" else None)
         return net(x)
@@ -174,7 +178,9 @@ def main():
                                f"{args.arch} (reference default constructor) forward on a batch of {B} {Ww}x{Hh} RGB images per GPU, fp32"
                                + ((f", reflect-padded to the enclosing {harness.square_side(Hh, Ww)}-pixel square, cropped and clamped after"
                                    if args.arch == "AST" else f", reflect-padded to multiples of {need}, cropped and clamped after")
-                                  if script_path else ""),
+                                  if script_path and not args.crop_size else
+                                  (f", reflect-padded to multiples of 8, restored as {args.crop_size}x{args.crop_size} tiles with "
+                                   f"overlap {args.overlap_size} and mean-blended" if args.crop_size else "")),
                    "batch_per_gpu": B, "height": Hh, "width": Ww, "sharding": "images round-robin over ranks, no collective"},
     }
     if flops_img and not script_path:
