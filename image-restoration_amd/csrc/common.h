@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -259,6 +260,13 @@ void set_current_clock(KernelClock* c);
 // installed, brackets the launch with HIP events.
 // Returns a pointer that stays valid for the life of the process (labels carry shapes).
 const char* intern_label(const char* fmt, ...);
+// hipFuncSetAttribute(..., MaxDynamicSharedMemorySize) takes effect on the current device only: a call
+// site keeps one of these (static) and the attribute is set once per device that launches from it.
+struct DynLdsOnce {
+  std::atomic<uint64_t> devices{0};   // bit d: done on device d (devices past 63 set it every time)
+};
+void allow_dynamic_lds(DynLdsOnce& once, const void* kernel, int bytes);
+
 struct Scope {
   Scope(const char* name, double flops, double bytes, hipStream_t s);
   ~Scope();

@@ -334,12 +334,8 @@ void launch_cross_window_attention(TV q, TV kv, TV out, int B, int C, int heads,
 #define JIRF_CW_CASE(HD)                                                                                  \
   do {                                                                                                    \
     const size_t smem = (size_t)4 * 64 * (HD + 4) * sizeof(float);                                        \
-    static bool attr = false;                                                                             \
-    if (!attr) {                                                                                          \
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cross_win_attn_kernel<HD>),        \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));        \
-      attr = true;                                                                                        \
-    }                                                                                                     \
+    static DynLdsOnce once;                                        \
+    allow_dynamic_lds(once, reinterpret_cast<const void*>(cross_win_attn_kernel<HD>), 128 * 1024); \
     hipLaunchKernelGGL((cross_win_attn_kernel<HD>), grid, block, smem, s, q.p, q.bs, kv.p, kv.bs, out.p,  \
                        out.bs, C, heads, H, W, scale, n_tasks);                                           \
   } while (0)

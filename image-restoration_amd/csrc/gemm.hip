@@ -775,12 +775,8 @@ static bool try_launch_xs3(const GemmArgs& a, int loader, bool vec, hipStream_t 
   const dim3 grid((unsigned)(tiles_n * a.B)), block(256);
 #define JIRF_X3_CASE(LD, V)                                                                            \
   do {                                                                                                 \
-    static bool attr = false;                                                                          \
-    if (!attr) {                                                                                       \
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_xs3_kernel<LD, V>),        \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));      \
-      attr = true;                                                                                     \
-    }                                                                                                  \
+    static DynLdsOnce once;                                        \
+    allow_dynamic_lds(once, reinterpret_cast<const void*>(gemm_xs3_kernel<LD, V>), 96 * 1024); \
     hipLaunchKernelGGL((gemm_xs3_kernel<LD, V>), grid, block, smem, s, a, tiles_n);                    \
   } while (0)
   if (loader == LD_LN) {
@@ -811,12 +807,8 @@ static void launch_xs(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
   const dim3 grid((unsigned)(tiles_n * a.B), (unsigned)msplit), block(256);
 #define JIRF_XS_CASE(LD, V)                                                                        \
   do {                                                                                             \
-    static bool attr = false;                                                                      \
-    if (!attr) {                                                                                   \
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_xs_kernel<BN, TNW, LD, V>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));  \
-      attr = true;                                                                                 \
-    }                                                                                              \
+    static DynLdsOnce once;                                        \
+    allow_dynamic_lds(once, reinterpret_cast<const void*>(gemm_xs_kernel<BN, TNW, LD, V>), 80 * 1024); \
     hipLaunchKernelGGL((gemm_xs_kernel<BN, TNW, LD, V>), grid, block, smem, s, a, tiles_n);        \
   } while (0)
   switch (loader) {

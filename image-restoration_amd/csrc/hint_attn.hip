@@ -516,12 +516,8 @@ static void launch_chan_stats96(const StatsArgs& st, int nb, hipStream_t s) {
   const size_t smem = (size_t)(2 + (DO_QK ? 2 : 0) + (need_c ? 2 : 0)) * SQ_T * ST_LD * sizeof(float);
 #define JIRF_SQ_CASE(V)                                                                              \
   do {                                                                                               \
-    static bool attr = false;                                                                        \
-    if (!attr) {                                                                                     \
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chan_stats96_kernel<DO_QK, DO_GRAM, V>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));    \
-      attr = true;                                                                                   \
-    }                                                                                                \
+    static DynLdsOnce once;                                        \
+    allow_dynamic_lds(once, reinterpret_cast<const void*>(chan_stats96_kernel<DO_QK, DO_GRAM, V>), 80 * 1024); \
     hipLaunchKernelGGL((chan_stats96_kernel<DO_QK, DO_GRAM, V>), grid, block, smem, s, st);          \
   } while (0)
   if (vec) JIRF_SQ_CASE(true); else JIRF_SQ_CASE(false);
@@ -1153,14 +1149,9 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     const size_t smem_c = ((size_t)3 * cmax + (2 * cmax + 31) / 32 * 32) * GA_LD * 4;
     JIRF_REQUIRE(smem_a <= 160 * 1024 && smem_c <= 160 * 1024, JIRF_EINVAL,
                  "hint attention: channel group of %d does not fit LDS (%zu / %zu bytes)", cmax, smem_a, smem_c);
-    static bool attr_set = false;
-    if (!attr_set) {
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_softmax_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_modulate_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    static DynLdsOnce once_softmax, once_modulate;
+    allow_dynamic_lds(once_softmax, reinterpret_cast<const void*>(group_softmax_kernel), 160 * 1024);
+    allow_dynamic_lds(once_modulate, reinterpret_cast<const void*>(group_modulate_kernel), 160 * 1024);
     {
       Scope scope(intern_label("hint_group_softmax C%d", C), 0.0, 12.0 * B * (double)C * C, s);
       hipLaunchKernelGGL(group_softmax_kernel, dim3(ga.sm_chunks, B), dim3(256), smem_a, s, ga);
@@ -1333,12 +1324,8 @@ void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const flo
     ha.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
     ha.s_qk = sc.s_qk; ha.rq = sc.rq; ha.rk = sc.rk; ha.temperature = temperature;
     ha.ca_w = ca_w; ha.ca_b = ca_b; ha.att_t = sc.att_t;
-    static bool attr_set = false;
-    if (!attr_set) {
-      JIRF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(head_attn_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    static DynLdsOnce once;
+    allow_dynamic_lds(once, reinterpret_cast<const void*>(head_attn_kernel), 160 * 1024);
     Scope scope(intern_label("head_attn C%d ch%d", C, ch), 4.0 * ch * (double)ch * ch * heads * B,
                 8.0 * B * (double)C * C, s);
     hipLaunchKernelGGL(head_attn_kernel, dim3(heads, B), dim3(256), smem, s, ha);

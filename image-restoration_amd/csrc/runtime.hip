@@ -334,4 +334,13 @@ int Net::set_param(const char* key_c, const void* data, int dtype, const int64_t
   return JIRF_OK;
 }
 
+void allow_dynamic_lds(DynLdsOnce& once, const void* kernel, int bytes) {
+  int dev = 0;
+  JIRF_HIP_CHECK(hipGetDevice(&dev));
+  const uint64_t bit = dev >= 0 && dev < 64 ? (uint64_t)1 << dev : 0;
+  if (bit && (once.devices.load(std::memory_order_acquire) & bit)) return;
+  JIRF_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (bit) once.devices.fetch_or(bit, std::memory_order_release);
+}
+
 }  // namespace jirf
