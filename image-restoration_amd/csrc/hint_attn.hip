@@ -855,18 +855,19 @@ __global__ __launch_bounds__(GM_THREADS) void group_modulate_kernel(const GroupA
   const int g = b / a.ipg;
   const int nj = min(GA_JC, c - j0);
   const int mp2 = (2 * c + 31) / 32 * 32, mp1 = (c + 31) / 32 * 32;
-  float* Xs = reinterpret_cast<float*>(gm_smem);   // [c][GA_LD]  softmax chunk
-  float* XP = Xs + c * GA_LD;                      // [c][GA_LD]  X + pooled cache
-  float* Ys = XP + c * GA_LD;                      // [c][GA_LD]
-  float* Zs = Ys + c * GA_LD;                      // [mp2][GA_LD]
+  const int ce = (c + 1) & ~1;                     // an MFMA step takes two rows: odd c gets a zero row
+  float* Xs = reinterpret_cast<float*>(gm_smem);   // [ce][GA_LD]  softmax chunk
+  float* XP = Xs + ce * GA_LD;                     // [ce][GA_LD]  X + pooled cache
+  float* Ys = XP + ce * GA_LD;                     // [ce][GA_LD]
+  float* Zs = Ys + ce * GA_LD;                     // [mp2][GA_LD]
   float* __restrict__ att_nat = a.att_nat + (long)b * C * C;
   const float* __restrict__ pg = a.pooled_g + (long)g * a.psum + a.poff[gi];
 
 #pragma unroll 4
-  for (int e = tid; e < c * GA_JC; e += GM_THREADS) {
+  for (int e = tid; e < ce * GA_JC; e += GM_THREADS) {
     const int r = e >> 5, jj = e & 31;
     float x = 0.f, xp = 0.f;
-    if (jj < nj) {
+    if (jj < nj && r < c) {
       x = att_nat[(long)(off + r) * C + off + j0 + jj];
       xp = x + pg[r * c + j0 + jj];
     }
@@ -876,6 +877,32 @@ __global__ __launch_bounds__(GM_THREADS) void group_modulate_kernel(const GroupA
   __syncthreads();
 
   typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  // 32 x 32 x c product: weight fragments in explicit batches of GM_KB k-steps, the next batch in flight
+  // while the current one is multiplied (left to the compiler the loop is not unrolled and every MFMA
+  // waits for its own L2 round trip)
+  constexpr int GM_KB = 6;   // group sizes are multiples of 12 for the shipped widths: c / 2 k-steps
+  const int nks = (c + 1) >> 1;
+  auto tile_product = [&](f32x16_t& acc, const float* __restrict__ ap, const int mp, const float* __restrict__ bp) {
+    float av[GM_KB], an[GM_KB];
+    const int full = nks / GM_KB * GM_KB;
+    if (full > 0) {
+#pragma unroll
+      for (int i = 0; i < GM_KB; ++i) av[i] = ap[(long)(2 * i) * mp];
+    }
+    for (int ks = 0; ks < full; ks += GM_KB) {
+      const int kn = ks + GM_KB < full ? ks + GM_KB : ks;
+#pragma unroll
+      for (int i = 0; i < GM_KB; ++i) an[i] = ap[(long)(2 * (kn + i)) * mp];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GM_KB; ++i)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bp[(2 * (ks + i)) * GA_LD], acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < GM_KB; ++i) av[i] = an[i];
+    }
+    for (int ks = full; ks < nks; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(long)(2 * ks) * mp], bp[(2 * ks) * GA_LD], acc, 0, 0, 0);
+  };
   // Z = Ww XP + bw
   {
     const float* __restrict__ Wt = a.cw_wt[gi];
@@ -884,11 +911,7 @@ __global__ __launch_bounds__(GM_THREADS) void group_modulate_kernel(const GroupA
       f32x16_t acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* __restrict__ ap = Wt + (long)half * mp2 + mt * 32 + l31;
-      const float* __restrict__ bp = XP + half * GA_LD + l31;
-#pragma unroll 16
-      for (int k0 = 0; k0 < c; k0 += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(long)k0 * mp2], bp[k0 * GA_LD], acc, 0, 0, 0);
+      tile_product(acc, Wt + (long)half * mp2 + mt * 32 + l31, mp2, XP + half * GA_LD + l31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -897,9 +920,9 @@ __global__ __launch_bounds__(GM_THREADS) void group_modulate_kernel(const GroupA
     }
   }
   __syncthreads();
-  for (int e = tid; e < c * GA_JC; e += GM_THREADS) {
+  for (int e = tid; e < ce * GA_JC; e += GM_THREADS) {
     const int o = e >> 5, jj = e & 31;
-    Ys[o * GA_LD + jj] = jj < nj ? Xs[o * GA_LD + jj] * Zs[o * GA_LD + jj] + Zs[(c + o) * GA_LD + jj] : 0.f;
+    Ys[o * GA_LD + jj] = (jj < nj && o < c) ? Xs[o * GA_LD + jj] * Zs[o * GA_LD + jj] + Zs[(c + o) * GA_LD + jj] : 0.f;
   }
   __syncthreads();
   // att = Y * gelu(Wg Y + bg) + X
@@ -912,11 +935,7 @@ __global__ __launch_bounds__(GM_THREADS) void group_modulate_kernel(const GroupA
       f32x16_t acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* __restrict__ ap = Wt + (long)half * mp1 + mt * 32 + l31;
-      const float* __restrict__ bp = Ys + half * GA_LD + l31;
-#pragma unroll 16
-      for (int k0 = 0; k0 < c; k0 += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(long)k0 * mp1], bp[k0 * GA_LD], acc, 0, 0, 0);
+      tile_product(acc, Wt + (long)half * mp1 + mt * 32 + l31, mp1, Ys + half * GA_LD + l31);
       if (l31 < nj) {
         const int s = j0 + l31;
 #pragma unroll
@@ -991,14 +1010,16 @@ __global__ __launch_bounds__(256) void cache_update_kernel(const CacheUpdArgs a)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// enough workgroups to fill the chip, but at least 8 chunks (256 px) per split
+// enough workgroups to fill the chip, but at least 2 chunks (64 px) per split
 static int stats_splits(int tiles, int B, int P) {
   const int chunks = (P + ST_CH - 1) / ST_CH;
   const int want = (1024 + tiles * tiles * B - 1) / (tiles * tiles * B);
   // more slabs cost the reduction kernel time in proportion to splits * B: allow many only while
   // the batch is small
   const int cap = std::min(256, std::max(32, 512 / (tiles * tiles * B)));
-  return std::min(cap, std::max(1, std::min(want, chunks / 8)));
+  // a workgroup is latency-bound per chunk (one workgroup per CU, register double buffer only), so a
+  // small problem is cut down to 2 chunks (64 px) per split: measured faster than 4 or 8 at B = 1
+  return std::min(cap, std::max(1, std::min(want, chunks / 2)));
 }
 
 HintAttnShape hint_attn_shape(int B, int C, int P, int batch_mode) {
@@ -1021,7 +1042,7 @@ static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 void pack_hint_modulator(const float* w, int M, int K, std::vector<float>& out) {
   const int mp = (M + 31) / 32 * 32;
-  out.assign((size_t)K * mp, 0.f);
+  out.assign((size_t)((K + 1) & ~1) * mp, 0.f);   // an MFMA step takes two k rows: odd K gets a zero row
   for (int o = 0; o < M; ++o)
     for (int k = 0; k < K; ++k) out[(size_t)k * mp + o] = w[(size_t)o * K + k];
 }
@@ -1146,7 +1167,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     ga.s_qk = sc.s_qk; ga.rq = sc.rq; ga.rk = sc.rk; ga.temperature = w.temperature;
     ga.pooled = pooled; ga.pooled_g = sc.pooled_g; ga.att_t = sc.att_t; ga.att_nat = sc.att_nat;
     const size_t smem_a = (size_t)C * 8 + ((size_t)C + (C & 1)) * 4 + (size_t)std::min(rcs, cmax) * (cmax + 1) * 4;
-    const size_t smem_c = ((size_t)3 * cmax + (2 * cmax + 31) / 32 * 32) * GA_LD * 4;
+    const size_t smem_c = ((size_t)3 * ((cmax + 1) & ~1) + (2 * cmax + 31) / 32 * 32) * GA_LD * 4;
     JIRF_REQUIRE(smem_a <= 160 * 1024 && smem_c <= 160 * 1024, JIRF_EINVAL,
                  "hint attention: channel group of %d does not fit LDS (%zu / %zu bytes)", cmax, smem_a, smem_c);
     static DynLdsOnce once_softmax, once_modulate;

@@ -132,11 +132,14 @@ SMALL_CFG = dict(inp_channels=3, out_channels=3, dim=16, num_blocks=[1, 2, 2, 3]
                  dual_pixel_task=False)
 
 
-@pytest.mark.parametrize("cfg_name,H,W", [("small", 64, 96), ("small_biasfree", 40, 72), ("full", 64, 64)])
+@pytest.mark.parametrize("cfg_name,H,W", [("small", 64, 96), ("small_biasfree", 40, 72), ("full", 64, 64),
+                                          ("small_dim24", 32, 48)])
 def test_network_b1_cold_and_warm(cfg_name, H, W):
     cfg = ho.default_config() if cfg_name == "full" else dict(SMALL_CFG)
     if cfg_name == "small_biasfree":
         cfg.update(ln_type="BiasFree", bias=True)
+    if cfg_name == "small_dim24":       # channel groups of 6 / 12 / 18 and 9 / 18 / 27 ...: k-step counts off the batch size
+        cfg.update(dim=24)
     sd = make_hint_state(cfg, seed=3, gain=0.6)
     x1 = synthetic_images(1, H, W, seed=11, sigma=50)
     x2 = synthetic_images(1, H, W, seed=12, sigma=50)
