@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 // registers; the left / right neighbours come from the adjacent lanes (__shfl), only the lanes on
 // a tile edge touch memory for them.  One wave per task, no LDS, no barrier; every global access
 // is a 16-byte lane access on a contiguous row segment.
-template <int MODE, int PX>
+template <int MODE, int PX, int RFIX>
 __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __restrict__ x, long x_bs,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
@@ -379,17 +379,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
     for (int i = 0; i < 9; ++i) k[g][i] = conv[g] ? w[wch * 9 + i] : 0.f;
     bb[g] = (conv[g] && bias) ? bias[wch] : 0.f;
   }
-  Row ra[NP], rb[NP], rc[NP];
-#pragma unroll
-  for (int g = 0; g < NP; ++g) {
-    ra[g] = load_row(plane[g], ys - 1);
-    rb[g] = load_row(plane[g], ys);
-  }
   float* __restrict__ dst0 = y + (long)b * y_bs + (long)c * P + px;
-  for (int i = 0; i < R; ++i) {
-    const int oy = ys + i;
-#pragma unroll
-    for (int g = 0; g < NP; ++g) rc[g] = load_row(plane[g], oy + 1);
+  // one output row from the three input rows around it
+  auto emit = [&](const Row* ra, const Row* rb, const Row* rc, const int oy) {
     float res[NP][PX];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
@@ -424,10 +416,36 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
       if constexpr (PX == 4) *reinterpret_cast<float4*>(dst0 + (long)oy * W) = make_float4(o[0], o[1], o[2], o[3]);
       else *reinterpret_cast<float2*>(dst0 + (long)oy * W) = make_float2(o[0], o[1]);
     }
+  };
+  if constexpr (RFIX > 0) {
+    // fixed strip height: every input row of the strip is requested before the first output row is
+    // computed, so a wave keeps RFIX + 2 row loads in flight.  Used for the plain (one plane) form only:
+    // the gated forms, which read two planes a tensor half apart, measured slower this way (and with a
+    // one-row look-ahead) than with the rolling loop below
+    Row rows[RFIX + 2][NP];
+#pragma unroll
+    for (int i = 0; i < RFIX + 2; ++i)
+#pragma unroll
+      for (int g = 0; g < NP; ++g) rows[i][g] = load_row(plane[g], ys - 1 + i);
+#pragma unroll
+    for (int i = 0; i < RFIX; ++i) emit(rows[i], rows[i + 1], rows[i + 2], ys + i);
+  } else {
+    Row ra[NP], rb[NP], rc[NP];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
-      ra[g] = rb[g];
-      rb[g] = rc[g];
+      ra[g] = load_row(plane[g], ys - 1);
+      rb[g] = load_row(plane[g], ys);
+    }
+    for (int i = 0; i < R; ++i) {
+      const int oy = ys + i;
+#pragma unroll
+      for (int g = 0; g < NP; ++g) rc[g] = load_row(plane[g], oy + 1);
+      emit(ra, rb, rc, oy);
+#pragma unroll
+      for (int g = 0; g < NP; ++g) {
+        ra[g] = rb[g];
+        rb[g] = rc[g];
+      }
     }
   }
 }
@@ -459,11 +477,14 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
     const dim3 g2((unsigned)((n_tasks + 3) / 4), B);
 #define JIRF_DW_ROWS(M, WM, WC)                                                                                      \
   do {                                                                                                               \
-    if (PX == 4)                                                                                                     \
-      hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 4>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,     \
+    if (PX == 4 && R == 8 && M == 0)                                                                                 \
+      hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 4, 8>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,  \
+                         lx_log2, R, tx, strips, n_tasks, WM, WC);                                                   \
+    else if (PX == 4)                                                                                                \
+      hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 4, 0>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,  \
                          lx_log2, R, tx, strips, n_tasks, WM, WC);                                                   \
     else                                                                                                             \
-      hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 2>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,     \
+      hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 2, 0>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,  \
                          lx_log2, R, tx, strips, n_tasks, WM, WC);                                                   \
   } while (0)
     if (gate == 1) JIRF_DW_ROWS(1, 0, 0);
