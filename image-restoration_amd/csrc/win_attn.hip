@@ -4,8 +4,8 @@
 //
 // One wave per (window, head): lane n is token n of the 8 x 8 window (64 tokens = 64 lanes), so a
 // score row, its softmax, the ReLU^2 branch and the output row all live in one lane's registers
-// and need no cross-lane traffic.  K and V tiles (64 tokens x 32 dims) are staged in LDS and read
-// back as wave-uniform float4 broadcasts.  Roll, window partition and window reverse are pure
+// and need no cross-lane traffic.  The K tile, then the V tile (64 tokens x 32 dims) is staged in the
+// wave's LDS slot and read back as wave-uniform float4 broadcasts.  Roll, window partition and window reverse are pure
 // addressing: a token reads and writes pixel ((wy*8 + ty + shift) mod H, (wx*8 + tx + shift) mod W).
 //
 // The reference flattens q as [window, head] but k as [head, window] before its batched matmul
@@ -19,9 +19,8 @@ constexpr int WA_D = 32;       // head dim
 constexpr int WA_N = 64;       // tokens per window
 constexpr int WA_LD = 36;      // LDS row stride (floats): 16-byte aligned rows
 
-__global__ __launch_bounds__(256) void win_attn_kernel(const WinAttnArgs a, int n_tasks) {
-  __shared__ __attribute__((aligned(16))) float Ks[4][WA_N * WA_LD];
-  __shared__ __attribute__((aligned(16))) float Vs[4][WA_N * WA_LD];
+__global__ __launch_bounds__(256, 3) void win_attn_kernel(const WinAttnArgs a, int n_tasks) {
+  __shared__ __attribute__((aligned(16))) float KVs[4][WA_N * WA_LD];   // K during the scores, then V
   __shared__ float Ts[4][232];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int task = blockIdx.x * 4 + wave;
@@ -49,17 +48,16 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const WinAttnArgs a, int 
   };
   const long pq = pixel(w), pk = pixel(wk);
 
-  float* __restrict__ ks = Ks[wave];
-  float* __restrict__ vs = Vs[wave];
+  float* __restrict__ ks = KVs[wave];
+  float* __restrict__ vs = KVs[wave];
   float* __restrict__ ts = Ts[wave];
+  // one LDS tile per wave (three workgroups fit a CU instead of two): K goes in now, V waits in registers
+  // until the scores are done
+  float vreg[WA_D];
   {
     const float* __restrict__ kp = a.k.p + (long)img_k * a.k.bs + (long)(hk * WA_D) * P + pk;
-    const float* __restrict__ vp = a.v.p + (long)img * a.v.bs + (long)(h * WA_D) * P + pq;
-#pragma unroll 8
-    for (int e = 0; e < WA_D; ++e) {
-      ks[lane * WA_LD + e] = kp[(long)e * P];
-      vs[lane * WA_LD + e] = vp[(long)e * P];
-    }
+#pragma unroll
+    for (int e = 0; e < WA_D; ++e) ks[lane * WA_LD + e] = kp[(long)e * P];
     for (int i = lane; i < 225; i += 64) ts[i] = a.table[i * heads + h];
   }
   float q[WA_D];
@@ -67,6 +65,9 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const WinAttnArgs a, int 
     const float* __restrict__ qp = a.q.p + (long)img * a.q.bs + (long)(h * WA_D) * P + pq;
 #pragma unroll
     for (int e = 0; e < WA_D; ++e) q[e] = qp[(long)e * P] * a.scale;
+    const float* __restrict__ vp = a.v.p + (long)img * a.v.bs + (long)(h * WA_D) * P + pq;
+#pragma unroll
+    for (int e = 0; e < WA_D; ++e) vreg[e] = vp[(long)e * P];
   }
   // region id of this token on the shifted grid (Swin shift mask), from the window position
   int rid = 0;
@@ -105,21 +106,25 @@ __global__ __launch_bounds__(256) void win_attn_kernel(const WinAttnArgs a, int 
     sc[m] = s;
     mx = fmaxf(mx, s);
   }
-  float sum = 0.f;
-  float ex[WA_N];
+  // every lane has read K: the tile now takes V
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int m = 0; m < WA_N; ++m) {
-    ex[m] = expf(sc[m] - mx);
-    sum += ex[m];
-  }
+  for (int e = 0; e < WA_D; ++e) vs[lane * WA_LD + e] = vreg[e];
+  float sum = 0.f;
+#pragma unroll
+  for (int m = 0; m < WA_N; ++m) sum += expf(sc[m] - mx);
   const float inv = 1.0f / sum;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   float o[WA_D];
 #pragma unroll
   for (int e = 0; e < WA_D; ++e) o[e] = 0.f;
 #pragma unroll
   for (int m = 0; m < WA_N; ++m) {
     const float r = fmaxf(sc[m], 0.f);
-    const float p = (ex[m] * inv) * a.w_softmax + (r * r) * a.w_relu2;
+    const float p = (expf(sc[m] - mx) * inv) * a.w_softmax + (r * r) * a.w_relu2;
     const float4* __restrict__ vr = reinterpret_cast<const float4*>(&vs[m * WA_LD]);
 #pragma unroll
     for (int e4 = 0; e4 < WA_D / 4; ++e4) {
