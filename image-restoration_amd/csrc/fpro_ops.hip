@@ -293,6 +293,39 @@ __global__ __launch_bounds__(256) void cross_win_attn_kernel(const float* __rest
   }
   wave_sync();
   float* __restrict__ ob = out + (long)img * o_bs;
+  if constexpr (HD <= 48) if (64 % heads == 0) {
+    // All HD accumulators fit in registers: the wave's outputs are exchanged through its LDS tile so that
+    // the stores run along pixels.  The flat index f = (h * HD + d) * 64 + n of this wave covers the
+    // 64 / heads tokens [h * 64 / heads, ...) with all C channels; written per lane they would go to 64
+    // different channel planes (one cache line each).
+    float o[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      const float p = sc[m] * inv;
+      const float4* __restrict__ vr = reinterpret_cast<const float4*>(&T[m * LD]);
+#pragma unroll
+      for (int e4 = 0; e4 < HD / 4; ++e4) {
+        const float4 v4 = vr[e4];
+        o[4 * e4 + 0] = fmaf(p, v4.x, o[4 * e4 + 0]);
+        o[4 * e4 + 1] = fmaf(p, v4.y, o[4 * e4 + 1]);
+        o[4 * e4 + 2] = fmaf(p, v4.z, o[4 * e4 + 2]);
+        o[4 * e4 + 3] = fmaf(p, v4.w, o[4 * e4 + 3]);
+      }
+    }
+    wave_sync();   // every lane is done reading V
+#pragma unroll
+    for (int e = 0; e < HD; ++e) T[e * 64 + lane] = o[e];   // local flat index f' = d * 64 + n
+    wave_sync();
+    const int tpw = 64 / heads;            // tokens this wave produces (heads divides 64)
+    const int tok0 = h * tpw;
+    for (int idx = lane; idx < 64 * HD; idx += 64) {
+      const int c2 = idx / tpw, tl = idx - c2 * tpw;
+      ob[(long)c2 * P + pixel(tok0 + tl)] = T[tl * C + c2];
+    }
+    return;
+  }
   // the output in chunks of 16 dims keeps the accumulators in registers for any HD
 #pragma unroll
   for (int d0 = 0; d0 < HD; d0 += 16) {
