@@ -594,12 +594,15 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __rest
 
 bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
   auto al = [](const float* p, long bs) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && bs % 4 == 0; };
-  const bool shape_ok = a.M >= 1 && a.M <= 4 && a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Hin == a.H &&
+  // up to 4 output channels with 4 rows per lane; 8 with 2 rows, 16 with 1 row (the quarter-width dense
+  // 3x3 of AST's FRFN at its two finest levels): 64 accumulators per lane in every case
+  const bool m_ok = (a.M >= 1 && a.M <= 4) || a.M == 8 || a.M == 16;
+  const bool shape_ok = m_ok && a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Hin == a.H &&
                         a.Win == a.W && a.W % 4 == 0 && (a.epi == EP_STORE || a.epi == EP_RESID) && a.wt_bs == 0 &&
                         al(a.x.p, a.x.bs) && al(a.y.p, a.y.bs) && (a.epi != EP_RESID || al(a.r.p, a.r.bs));
   if (!shape_ok) return false;
   const int H = a.H, W = a.W;
-  constexpr int R = 4;
+  const int R = a.M <= 4 ? 4 : a.M == 8 ? 2 : 1;
   int lx_log2 = 0;
   while ((1 << lx_log2) < 64 && (4 << lx_log2) < W) ++lx_log2;
   const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
@@ -607,14 +610,16 @@ bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
   const int n_tasks = tiles_x * strips;
   const dim3 grid((unsigned)((n_tasks + 3) / 4), a.B), block(256);
   const float* res = a.epi == EP_RESID ? a.r.p : nullptr;
-#define JIRF_FEWOUT(CO)                                                                              \
-  hipLaunchKernelGGL((conv3x3_fewout_kernel<CO, R>), grid, block, 0, s, a.x.p, a.x.bs, a.wt, a.Mpad, a.bias, res, \
+#define JIRF_FEWOUT(CO, RR)                                                                            \
+  hipLaunchKernelGGL((conv3x3_fewout_kernel<CO, RR>), grid, block, 0, s, a.x.p, a.x.bs, a.wt, a.Mpad, a.bias, res, \
                      a.r.bs, a.y.p, a.y.bs, a.Cin, H, W, lx_log2, tiles_x, n_tasks)
   switch (a.M) {
-    case 1: JIRF_FEWOUT(1); break;
-    case 2: JIRF_FEWOUT(2); break;
-    case 3: JIRF_FEWOUT(3); break;
-    default: JIRF_FEWOUT(4); break;
+    case 1: JIRF_FEWOUT(1, 4); break;
+    case 2: JIRF_FEWOUT(2, 4); break;
+    case 3: JIRF_FEWOUT(3, 4); break;
+    case 4: JIRF_FEWOUT(4, 4); break;
+    case 8: JIRF_FEWOUT(8, 2); break;
+    default: JIRF_FEWOUT(16, 1); break;
   }
 #undef JIRF_FEWOUT
   JIRF_HIP_CHECK(hipGetLastError());
