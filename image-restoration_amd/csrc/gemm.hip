@@ -927,7 +927,10 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
                   (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
   if ((xs || (gemm_split_bf16_enabled() && a.K <= 128 && loader == LD_PLAIN)) && try_launch_xs3(a, loader, vec, s)) return;
   if (xs) {
-    if (a.K <= 128) launch_xs_bn<128>(a, loader, vec, s);
+    // 128-pixel tiles need K <= 128 (LDS) and enough of them: an underfilled grid does better with 64-pixel
+    // tiles (half the tile load per workgroup) than with more row splits of the wide ones
+    const long wide_tiles = (long)((a.P + 127) / 128) * a.B;
+    if (a.K <= 128 && wide_tiles >= 512) launch_xs_bn<128>(a, loader, vec, s);
     else launch_xs_bn<64>(a, loader, vec, s);
     return;
   }
