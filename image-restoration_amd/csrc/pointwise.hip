@@ -430,19 +430,43 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < RFIX; ++i) emit(rows[i], rows[i + 1], rows[i + 2], ys + i);
   } else {
+    // the second plane of MODE 2 / 3 is multiplied in as it is: only its centre row is read, without
+    // the neighbours
+    constexpr bool PLAIN2 = MODE == 2 || MODE == 3;
+    auto load_center = [&](const float* __restrict__ pl, int yy) {
+      Row r;
+#pragma unroll
+      for (int j = 0; j < PX + 2; ++j) r.v[j] = 0.f;
+      if (x_ok && yy < H) {
+        const float* __restrict__ p = pl + (long)yy * W + px;
+        if constexpr (PX == 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(p);
+          r.v[1] = t4.x; r.v[2] = t4.y; r.v[3] = t4.z; r.v[4] = t4.w;
+        } else {
+          const float2 t2 = *reinterpret_cast<const float2*>(p);
+          r.v[1] = t2.x; r.v[2] = t2.y;
+        }
+      }
+      return r;
+    };
     Row ra[NP], rb[NP], rc[NP];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
+      if (PLAIN2 && g == 1) continue;
       ra[g] = load_row(plane[g], ys - 1);
       rb[g] = load_row(plane[g], ys);
     }
     for (int i = 0; i < R; ++i) {
       const int oy = ys + i;
 #pragma unroll
-      for (int g = 0; g < NP; ++g) rc[g] = load_row(plane[g], oy + 1);
+      for (int g = 0; g < NP; ++g) {
+        if (PLAIN2 && g == 1) rb[g] = load_center(plane[g], oy);
+        else rc[g] = load_row(plane[g], oy + 1);
+      }
       emit(ra, rb, rc, oy);
 #pragma unroll
       for (int g = 0; g < NP; ++g) {
+        if (PLAIN2 && g == 1) continue;
         ra[g] = rb[g];
         rb[g] = rc[g];
       }
