@@ -15,3 +15,9 @@ def timeit(f, bytes_, reps=20):
 print("copy      GB/s", round(timeit(lambda: c.copy_(a), 8 * n)))
 print("mul 2r1w  GB/s", round(timeit(lambda: torch.mul(a, b, out=c), 12 * n)))
 print("read-only GB/s", round(timeit(lambda: a.sum(), 4 * n)))
+# write-only and write-heavy mixes (the LayerNorm GEMM of the benchmark reads 96 and writes 510 channels)
+d = torch.empty(5 * n // 2, device="cuda")
+print("write-only GB/s", round(timeit(lambda: d.fill_(1.0), 4 * d.numel())))
+small = torch.randn(n // 5, device="cuda")
+big = torch.empty(5, n // 5, device="cuda")
+print("1r5w      GB/s", round(timeit(lambda: big.copy_(small[None, :].expand(5, -1)), 4 * (small.numel() + big.numel()))))
