@@ -15,6 +15,8 @@
 
 namespace jirf {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 constexpr int WA_D = 32;       // head dim
 constexpr int WA_N = 64;       // tokens per window
 constexpr int WA_LD = 36;      // LDS row stride (floats): 16-byte aligned rows
@@ -140,6 +142,156 @@ __global__ __launch_bounds__(256, 3) void win_attn_kernel(const WinAttnArgs a, i
   for (int e = 0; e < WA_D; ++e) op[(long)e * P] = o[e];
 }
 
+// ---- matrix-core form ------------------------------------------------------------------------------------
+// The vector-ALU kernel above is bound by LDS bandwidth: every K / V row is a 16-byte broadcast read,
+// 1024 of them per (window, head).  Here the two 64 x 64 x 32 products run on fp32 MFMA (32x32x2) with
+// operands taken straight from registers:
+//   S^T[m][n] = sum_e K[m][e] Q[n][e]      A = K fragments, B = Q fragments (both loaded from global in
+//                                          fragment layout: lane l holds row / column l & 31, k = l >> 5)
+// Computing the scores transposed puts one query n in a lane's column, so its softmax runs over that
+// lane's 32 registers plus the partner lane (l ^ 32) and needs one cross-lane exchange.
+//   O^T[e][n] = sum_m V[m][e] P[m][n]      B = the probability registers as they are: register r of lane
+//                                          half h holds key m = 32 mt + (r & 3) + 8 (r >> 2) + 4 h, and the
+//                                          reduction may visit the keys in any order as long as A follows:
+//                                          A = V[m_h][e] read from the wave's LDS tile (lane = channel e).
+constexpr int WA_LDV = 40;     // V tile row stride: rows m and m + 4 land on disjoint bank halves
+
+__global__ __launch_bounds__(256, 3) void win_attn_mfma_kernel(const WinAttnArgs a, int n_tasks) {
+  __shared__ float Vs[4][WA_N * WA_LDV];
+  __shared__ float Ts[4][232];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= n_tasks) return;   // whole wave exits together; only wave-level synchronisation below
+  const int H = a.H, W = a.W, heads = a.heads;
+  const int nwx = W >> 3, nW = (H >> 3) * nwx;
+  const long P = (long)H * W;
+  const int gw = task / heads, h = task - gw * heads;
+  const int img = gw / nW, w = gw - img * nW;
+  const int span = a.coupled ? a.B * nW : nW;
+  const int j = (a.coupled ? gw : w) * heads + h;
+  const int hk = j / span, bk = j - hk * span;
+  const int img_k = a.coupled ? bk / nW : img;
+  const int wk = a.coupled ? bk - img_k * nW : bk;
+  auto pixel = [&](int win, int t) {
+    const int wy = win / nwx, wx = win - wy * nwx;
+    int y = wy * 8 + (t >> 3) + a.shift, x = wx * 8 + (t & 7) + a.shift;
+    if (y >= H) y -= H;
+    if (x >= W) x -= W;
+    return (long)y * W + x;
+  };
+  float* __restrict__ vs = Vs[wave];
+  float* __restrict__ ts = Ts[wave];
+
+  // ---- operand fragments -----------------------------------------------------------------------------------
+  float kf[2][WA_D / 2], qf[2][WA_D / 2];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const float* __restrict__ kp = a.k.p + (long)img_k * a.k.bs + (long)(hk * WA_D + half) * P + pixel(wk, t2 * 32 + l31);
+    const float* __restrict__ qp = a.q.p + (long)img * a.q.bs + (long)(h * WA_D + half) * P + pixel(w, t2 * 32 + l31);
+#pragma unroll
+    for (int s = 0; s < WA_D / 2; ++s) {
+      kf[t2][s] = kp[(long)(2 * s) * P];
+      qf[t2][s] = qp[(long)(2 * s) * P] * a.scale;
+    }
+  }
+  {
+    const float* __restrict__ vp = a.v.p + (long)img * a.v.bs + (long)(h * WA_D) * P + pixel(w, lane);
+#pragma unroll 8
+    for (int e = 0; e < WA_D; ++e) vs[lane * WA_LDV + e] = vp[(long)e * P];
+    for (int i = lane; i < 225; i += 64) ts[i] = a.table[i * heads + h];
+  }
+  // Swin shift-mask region of token `lane` on the shifted grid
+  int rid_tok = 0;
+  if (a.shift) {
+    const int wy = w / nwx, wx = w - wy * nwx;
+    const int sy = wy * 8 + (lane >> 3), sx = wx * 8 + (lane & 7);
+    const int rh = sy < H - 8 ? 0 : (sy < H - a.shift ? 1 : 2);
+    const int rw = sx < W - 8 ? 0 : (sx < W - a.shift ? 1 : 2);
+    rid_tok = 3 * rh + rw;
+  }
+
+  // ---- S^T = K Q^T ---------------------------------------------------------------------------------------------
+  f32x16 S[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[mt][nt][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < WA_D / 2; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        S[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[mt][s], qf[nt][s], S[mt][nt], 0, 0, 0);
+
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // ---- bias, mask, the two branches: per query column ----------------------------------------------------------
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = nt * 32 + l31;
+    const int ny = n >> 3, nx = n & 7;
+    const int rid_n = __shfl(rid_tok, n);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float sc = S[mt][nt][r] + ts[(ny - (m >> 3) + 7) * 15 + (nx - (m & 7) + 7)];
+        if (a.shift) {
+          const int rid_m = __shfl(rid_tok, m);
+          if (rid_m != rid_n) sc += -100.0f;
+        }
+        S[mt][nt][r] = sc;
+        mx = fmaxf(mx, sc);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += expf(S[mt][nt][r] - mx);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sc = S[mt][nt][r];
+        const float rl = fmaxf(sc, 0.f);
+        S[mt][nt][r] = (expf(sc - mx) * inv) * a.w_softmax + (rl * rl) * a.w_relu2;
+      }
+  }
+
+  // ---- O^T = V^T P^T -------------------------------------------------------------------------------------------
+  f32x16 O[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[nt][r] = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float av = vs[m * WA_LDV + l31];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) O[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, S[mt][nt][r], O[nt], 0, 0, 0);
+    }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    float* __restrict__ op = a.out.p + (long)img * a.out.bs + (long)(h * WA_D + 4 * half) * P + pixel(w, nt * 32 + l31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) op[(long)((r & 3) + 8 * (r >> 2)) * P] = O[nt][r];
+  }
+}
+
 void launch_window_attention(const WinAttnArgs& a, hipStream_t s) {
   JIRF_REQUIRE(a.B > 0 && a.heads > 0 && a.C == a.heads * WA_D, JIRF_EINVAL,
                "window attention: C=%d heads=%d (only head_dim 32 is built)", a.C, a.heads);
@@ -149,7 +301,11 @@ void launch_window_attention(const WinAttnArgs& a, hipStream_t s) {
   const int n_tasks = a.B * (a.H / 8) * (a.W / 8) * a.heads;
   const double px = (double)a.B * a.H * a.W;
   Scope sc(intern_label("win_attn C%d H%d W%d", a.C, a.H, a.W), 4.0 * 64 * a.C * px, 16.0 * a.C * px, s);
-  hipLaunchKernelGGL(win_attn_kernel, dim3((n_tasks + 3) / 4), dim3(256), 0, s, a, n_tasks);
+  static const bool valu = std::getenv("JIRF_WINATTN_VALU") != nullptr;
+  if (valu)
+    hipLaunchKernelGGL(win_attn_kernel, dim3((n_tasks + 3) / 4), dim3(256), 0, s, a, n_tasks);
+  else
+    hipLaunchKernelGGL(win_attn_mfma_kernel, dim3((n_tasks + 3) / 4), dim3(256), 0, s, a, n_tasks);
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
