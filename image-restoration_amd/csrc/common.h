@@ -260,6 +260,17 @@ void set_current_clock(KernelClock* c);
 // installed, brackets the launch with HIP events.
 // Returns a pointer that stays valid for the life of the process (labels carry shapes).
 const char* intern_label(const char* fmt, ...);
+#ifdef __HIPCC__
+// Blocks b and b + 8 share an XCD (round-robin dispatch).  Remap so that consecutive logical
+// tiles — which share the same activation columns — land on one XCD's L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = id & 7, local = id >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}
+#endif
+
 // hipFuncSetAttribute(..., MaxDynamicSharedMemorySize) takes effect on the current device only: a call
 // site keeps one of these (static) and the attribute is set once per device that launches from it.
 struct DynLdsOnce {

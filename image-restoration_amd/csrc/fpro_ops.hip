@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void cross_win_attn_kernel(const float* __rest
   constexpr int LD = HD + 4;
   extern __shared__ __attribute__((aligned(16))) float cw_smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + wave;
+  const int task = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // neighbouring windows share an XCD's L2
   if (task >= n_tasks) return;   // whole wave; only wave-level synchronisation below
   float* __restrict__ T = cw_smem + wave * 64 * LD;
   const int nwx = W >> 3, nW = (H >> 3) * nwx;

@@ -27,15 +27,6 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
-// Blocks b and b + 8 share an XCD (round-robin dispatch).  Remap so that consecutive logical
-// tiles — which share the same activation columns — land on one XCD's L2.  Bijective for any n.
-__device__ __forceinline__ int xcd_remap(int id, int n) {
-  const int q = n >> 3, r = n & 7;
-  const int xcd = id & 7, local = id >> 3;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + local;
-}
-
 // Epilogue of one 32 x 32 accumulator tile: rows row0 + (r & 3) + 8 * (r >> 2) (row0 already holds
 // the lane half's + 4), column `col` (< P).  Everything the epilogue reads is gathered first so
 // the 16 loads are in flight together — output and residual may be the same buffer, which keeps

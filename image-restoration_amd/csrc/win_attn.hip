@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_kernel(const WinAttnArgs a, i
   __shared__ __attribute__((aligned(16))) float KVs[4][WA_N * WA_LD];   // K during the scores, then V
   __shared__ float Ts[4][232];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + wave;
+  const int task = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // neighbouring windows share an XCD's L2
   if (task >= n_tasks) return;   // whole wave exits together; no block-wide barrier is used below
   const int H = a.H, W = a.W, heads = a.heads;
   const int nwx = W >> 3, nW = (H >> 3) * nwx;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_mfma_kernel(const WinAttnArgs
   __shared__ float Ts[4][232];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int task = blockIdx.x * 4 + wave;
+  const int task = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // neighbouring windows share an XCD's L2
   if (task >= n_tasks) return;   // whole wave exits together; only wave-level synchronisation below
   const int H = a.H, W = a.W, heads = a.heads;
   const int nwx = W >> 3, nW = (H >> 3) * nwx;
