@@ -354,6 +354,138 @@ __global__ __launch_bounds__(256) void cross_win_attn_kernel(const float* __rest
   }
 }
 
+// ---- matrix-core form of the cross attention (head dims up to 64, heads dividing 64) ---------------------
+// The vector-ALU kernel above reads every K / V row as 16-byte LDS broadcasts and is bound by LDS
+// bandwidth.  Here S^T[m][n] = sum_d K[m][d] Q[n][d] runs on fp32 MFMA (32x32x2) with both operands
+// loaded from global in fragment layout; a query's softmax then lives in one lane's column (32 registers
+// plus the partner lane).  O^T[d][n] = sum_m V[m][d] P[m][n] takes the probability registers as its B
+// operand in place and V[m][d] from the wave's LDS tile (zero columns pad the head dim to 32 d-rows per
+// tile).  The outputs leave through the same LDS tile in the reference's flat order, as above.
+typedef float cw_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CWM_LD = 72;   // V tile row stride: rows m and m + 4 on disjoint bank halves; >= 64 columns
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void cross_win_attn_mfma_kernel(const float* __restrict__ q, long q_bs,
+                                                                     const float* __restrict__ kv, long kv_bs,
+                                                                     float* __restrict__ out, long o_bs, int C,
+                                                                     int heads, int H, int W, float scale,
+                                                                     int n_tasks) {
+  constexpr int ET = (HD + 31) / 32;   // 32-row tiles of the output's d axis
+  constexpr int KS = HD / 2;           // MFMA steps of the score product
+  __shared__ float Tile[4][64 * CWM_LD];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int task = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  if (task >= n_tasks) return;   // whole wave; only wave-level synchronisation below
+  float* __restrict__ T = Tile[wave];
+  const int nwx = W >> 3, nW = (H >> 3) * nwx;
+  const long P = (long)H * W;
+  const int gw = task / heads, h = task - gw * heads;
+  const int img = gw / nW, w = gw - img * nW;
+  const int wy = w / nwx, wx = w - wy * nwx;
+  auto pixel = [&](int n) { return (long)(wy * 8 + (n >> 3)) * W + wx * 8 + (n & 7); };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  float kf[2][KS], qf[2][KS];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const long px = pixel(t2 * 32 + l31);
+    const float* __restrict__ kp = kv + (long)img * kv_bs + (long)(h * HD + half) * P + px;
+    const float* __restrict__ qp = q + (long)img * q_bs + (long)(h * HD + half) * P + px;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kf[t2][s] = kp[(long)(2 * s) * P];
+      qf[t2][s] = qp[(long)(2 * s) * P] * scale;
+    }
+  }
+  {
+    const float* __restrict__ vp = kv + (long)img * kv_bs + (long)(C + h * HD) * P + pixel(lane);
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) T[lane * CWM_LD + d] = vp[(long)d * P];
+#pragma unroll
+    for (int d = HD; d < ET * 32; ++d) T[lane * CWM_LD + d] = 0.f;
+  }
+  cw_f32x16 S[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[mt][nt][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        S[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[mt][s], qf[nt][s], S[mt][nt], 0, 0, 0);
+  // softmax over the keys, per query column
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[mt][nt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        S[mt][nt][r] = expf(S[mt][nt][r] - mx);
+        sum += S[mt][nt][r];
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[mt][nt][r] *= inv;
+  }
+  wave_sync();   // the V tile is complete
+  cw_f32x16 O[ET][2];
+#pragma unroll
+  for (int et = 0; et < ET; ++et)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[et][nt][r] = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        const float av = T[m * CWM_LD + et * 32 + l31];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          O[et][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, S[mt][nt][r], O[et][nt], 0, 0, 0);
+      }
+    }
+  wave_sync();   // every lane is done reading V: the tile now carries the outputs, flat index d * 64 + n
+#pragma unroll
+  for (int et = 0; et < ET; ++et)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = et * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (d < HD) T[d * 64 + nt * 32 + l31] = O[et][nt][r];
+      }
+  wave_sync();
+  float* __restrict__ ob = out + (long)img * o_bs;
+  const int tpw = 64 / heads, tok0 = h * tpw;
+  for (int idx = lane; idx < 64 * HD; idx += 64) {
+    const int c2 = idx / tpw, tl = idx - c2 * tpw;
+    ob[(long)c2 * P + pixel(tok0 + tl)] = T[tl * C + c2];
+  }
+}
+
 void launch_cross_window_attention(TV q, TV kv, TV out, int B, int C, int heads, int H, int W, hipStream_t s) {
   JIRF_REQUIRE(heads > 0 && C % heads == 0, JIRF_EINVAL, "cross window attention: C=%d heads=%d", C, heads);
   const int hd = C / heads;
@@ -372,6 +504,19 @@ void launch_cross_window_attention(TV q, TV kv, TV out, int B, int C, int heads,
     hipLaunchKernelGGL((cross_win_attn_kernel<HD>), grid, block, smem, s, q.p, q.bs, kv.p, kv.bs, out.p,  \
                        out.bs, C, heads, H, W, scale, n_tasks);                                           \
   } while (0)
+  static const bool valu = std::getenv("JIRF_CROSSWIN_VALU") != nullptr;
+  if (!valu && 64 % heads == 0 && (hd == 16 || hd == 32 || hd == 48 || hd == 64)) {
+#define JIRF_CWM_CASE(HD)                                                                                 \
+  hipLaunchKernelGGL((cross_win_attn_mfma_kernel<HD>), grid, block, 0, s, q.p, q.bs, kv.p, kv.bs, out.p,  \
+                     out.bs, C, heads, H, W, scale, n_tasks)
+    if (hd == 16) JIRF_CWM_CASE(16);
+    else if (hd == 32) JIRF_CWM_CASE(32);
+    else if (hd == 48) JIRF_CWM_CASE(48);
+    else JIRF_CWM_CASE(64);
+#undef JIRF_CWM_CASE
+    JIRF_HIP_CHECK(hipGetLastError());
+    return;
+  }
   switch (hd) {
     case 16: JIRF_CW_CASE(16); break;
     case 32: JIRF_CW_CASE(32); break;
