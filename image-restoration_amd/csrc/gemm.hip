@@ -408,27 +408,65 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   if constexpr (LOADER == LD_GATHER) kidx = a.kidx + (long)(b / a.imgs_per_group) * K;
 
   // ---- load the tile --------------------------------------------------------------------------
-  for (int s = tid; s < Kp * (BN / 4); s += 256) {
-    const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-    const int p = n0 + c4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < K && p < P) {
-      int row = k;
-      if constexpr (LOADER == LD_GATHER) row = kidx[k];
-      const float* __restrict__ src = xb + (long)row * P + p;
-      if constexpr (LOADER == LD_PLAIN) {
-        if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)row * P + p;
+  // In batches of XS_LB 16-byte loads per thread, all issued before the first LDS store: a loop of
+  // load - wait - store keeps one load in flight per thread and leaves the tile load latency-bound.
+  // The loads are unpredicated (clamped, always valid addresses; rejected slots are zeroed afterwards),
+  // since a predicated load makes the compiler wait at the join.
+  float* __restrict__ st_g = st_rs + BN;             // [Kp] LayerNorm weight (LD_LN)
+  float* __restrict__ st_b = st_g + Kp;              // [Kp] LayerNorm bias
+  if constexpr (LOADER == LD_LN) {
+    for (int k = tid; k < K; k += 256) {
+      st_g[k] = a.lnw[k];
+      st_b[k] = a.lnb ? a.lnb[k] : 0.f;
+    }
+  }
+  if constexpr (VEC) {
+    constexpr int XS_LB = 12;
+    const int total = Kp * (BN / 4);
+    const float* __restrict__ xb2 = LOADER == LD_PLAIN && a.k_split > 0 ? a.x2.p + (long)b * a.x2.bs : xb;
+    for (int s0 = tid; s0 < total; s0 += 256 * XS_LB) {
+      float4 v[XS_LB];
+      bool ok[XS_LB];
+#pragma unroll
+      for (int u = 0; u < XS_LB; ++u) {
+        const int s = s0 + u * 256;
+        const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+        const int p = n0 + c4;
+        ok[u] = s < total && k < K && p < P;
+        const int kc = min(k, K - 1);
+        int row = kc;
+        if constexpr (LOADER == LD_GATHER) row = kidx[kc];
+        const float* __restrict__ base = (LOADER == LD_PLAIN && kc < a.k_split) ? xb2 : xb;
+        v[u] = *reinterpret_cast<const float4*>(base + (long)row * P + (p < P ? p : 0));
       }
-      if constexpr (VEC) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
+#pragma unroll
+      for (int u = 0; u < XS_LB; ++u) {
+        const int s = s0 + u * 256;
+        if (s < total) {
+          const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+          *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  } else {
+    for (int s = tid; s < Kp * (BN / 4); s += 256) {
+      const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+      const int p = n0 + c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && p < P) {
+        int row = k;
+        if constexpr (LOADER == LD_GATHER) row = kidx[k];
+        const float* __restrict__ src = xb + (long)row * P + p;
+        if constexpr (LOADER == LD_PLAIN) {
+          if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)row * P + p;
+        }
         v.x = src[0];
         if (p + 1 < P) v.y = src[1];
         if (p + 2 < P) v.z = src[2];
         if (p + 3 < P) v.w = src[3];
       }
+      *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
     }
-    *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
   }
   __syncthreads();
   if constexpr (LOADER == LD_LN) {
@@ -447,10 +485,11 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
       st_rs[tid] = n0 + tid < P ? 1.0f / sqrtf(var / (float)K + 1e-5f) : 0.f;
     }
     __syncthreads();
+#pragma unroll 4
     for (int s = tid; s < K * (BN / 4); s += 256) {
       const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-      const float g = a.lnw[k];
-      const float be = a.lnb ? a.lnb[k] : 0.f;
+      const float g = st_g[k];
+      const float be = st_b[k];
       float4 v = *reinterpret_cast<float4*>(&Xs[k * BN + c4]);
       const float4 mu = *reinterpret_cast<const float4*>(&st_mu[c4]);
       const float4 rs = *reinterpret_cast<const float4*>(&st_rs[c4]);
@@ -790,7 +829,7 @@ template <int BN, int TNW>
 static void launch_xs(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
   const int tiles_n = (a.P + BN - 1) / BN;
   const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
-  const size_t smem = ((size_t)Kp * BN + 2 * BN) * sizeof(float);
+  const size_t smem = ((size_t)Kp * BN + 2 * BN + 2 * Kp) * sizeof(float);
   // fewer workgroups than twice the CUs: split the output-row tiles over gridDim.y (at least 4 per part)
   const int n_mt = (a.M + 31) / 32;
   int msplit = 1;
