@@ -559,8 +559,15 @@ __device__ __forceinline__ void reduce_slabs_part(T* __restrict__ base, long str
                                                   int part, T* __restrict__ red, int el, bool on) {
   T t = 0;
   if (on) {
-#pragma unroll 8
-    for (int sp = part; sp < splits; sp += 8) t += base[(long)sp * stride];
+    // four loads in flight per thread (clamped, unpredicated), added in slab order
+    for (int sp0 = part; sp0 < splits; sp0 += 32) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = base[(long)min(sp0 + 8 * u, splits - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (sp0 + 8 * u < splits) t += v[u];
+    }
   }
   red[part * 32 + el] = t;
   __syncthreads();

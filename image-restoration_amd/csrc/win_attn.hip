@@ -60,7 +60,12 @@ __global__ __launch_bounds__(256, 3) void win_attn_kernel(const WinAttnArgs a, i
     const float* __restrict__ kp = a.k.p + (long)img_k * a.k.bs + (long)(hk * WA_D) * P + pk;
 #pragma unroll
     for (int e = 0; e < WA_D; ++e) ks[lane * WA_LD + e] = kp[(long)e * P];
-    for (int i = lane; i < 225; i += 64) ts[i] = a.table[i * heads + h];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {   // 225 table entries: four unpredicated loads per lane, in flight together
+      const int i = lane + 64 * t4;
+      const float tv = a.table[min(i, 224) * heads + h];
+      if (i < 225) ts[i] = tv;
+    }
   }
   float q[WA_D];
   {
@@ -199,7 +204,12 @@ __global__ __launch_bounds__(256, 3) void win_attn_mfma_kernel(const WinAttnArgs
     const float* __restrict__ vp = a.v.p + (long)img * a.v.bs + (long)(h * WA_D) * P + pixel(w, lane);
 #pragma unroll 8
     for (int e = 0; e < WA_D; ++e) vs[lane * WA_LDV + e] = vp[(long)e * P];
-    for (int i = lane; i < 225; i += 64) ts[i] = a.table[i * heads + h];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {   // 225 table entries: four unpredicated loads per lane, in flight together
+      const int i = lane + 64 * t4;
+      const float tv = a.table[min(i, 224) * heads + h];
+      if (i < 225) ts[i] = tv;
+    }
   }
   // Swin shift-mask region of token `lane` on the shifted grid
   int rid_tok = 0;
