@@ -335,23 +335,35 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
   const bool x_ok = px < W;
 
   struct Row { float v[PX + 2]; };
-  auto load_row = [&](const float* __restrict__ plane, int yy) {
+  struct Raw { float m[PX]; };
+  // A row is fetched in two steps so that several rows can be in flight: `fetch` issues the 16-byte (8-byte)
+  // load from a clamped, always valid address with no predicate around it; `finish` zeroes what lies outside
+  // the image and gathers the left / right neighbours from the adjacent lanes (whole-wave DPP shifts; only
+  // the lanes on a tile edge touch memory for them).
+  auto fetch = [&](const float* __restrict__ plane, int yy) {
+    Raw r;
+    const float* __restrict__ p = plane + (long)min(max(yy, 0), H - 1) * W + (x_ok ? px : 0);
+    if constexpr (PX == 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(p);
+      r.m[0] = t4.x; r.m[1] = t4.y; r.m[2] = t4.z; r.m[3] = t4.w;
+    } else {
+      const float2 t2 = *reinterpret_cast<const float2*>(p);
+      r.m[0] = t2.x; r.m[1] = t2.y;
+    }
+    return r;
+  };
+  auto finish = [&](const Raw& raw, const float* __restrict__ plane, int yy) {
     Row r;
     const bool ok = x_ok && yy >= 0 && yy < H;
     float m[PX];
 #pragma unroll
-    for (int j = 0; j < PX; ++j) m[j] = 0.f;
+    for (int j = 0; j < PX; ++j) m[j] = ok ? raw.m[j] : 0.f;
+    // lane i takes lane i - 1's last pixel / lane i + 1's first pixel (wave_shr:1 / wave_shl:1)
+    float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m[PX - 1]),
+                                                                    __builtin_bit_cast(int, m[PX - 1]), 0x138, 0xf, 0xf, false));
+    float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m[0]),
+                                                                     __builtin_bit_cast(int, m[0]), 0x130, 0xf, 0xf, false));
     const float* __restrict__ p = plane + (long)yy * W + px;
-    if (ok) {
-      if constexpr (PX == 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(p);
-        m[0] = t4.x; m[1] = t4.y; m[2] = t4.z; m[3] = t4.w;
-      } else {
-        const float2 t2 = *reinterpret_cast<const float2*>(p);
-        m[0] = t2.x; m[1] = t2.y;
-      }
-    }
-    float l = __shfl_up(m[PX - 1], 1), rr = __shfl_down(m[0], 1);
     if (xq == 0) l = (ok && px > 0) ? p[-1] : 0.f;
     if (xq == LX - 1 || px + PX >= W) rr = (ok && px + PX < W) ? p[PX] : 0.f;
     r.v[0] = l;
@@ -360,6 +372,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
     r.v[PX + 1] = rr;
     return r;
   };
+  auto load_row = [&](const float* __restrict__ plane, int yy) { return finish(fetch(plane, yy), plane, yy); };
 
   // per-plane state
   float k[NP][9], bb[NP];
@@ -450,18 +463,28 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
       return r;
     };
     Row ra[NP], rb[NP], rc[NP];
+    Raw nx[NP];   // the next input row of every convolved plane, in flight while the current one is used
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
       if (PLAIN2 && g == 1) continue;
-      ra[g] = load_row(plane[g], ys - 1);
-      rb[g] = load_row(plane[g], ys);
+      const Raw r0 = fetch(plane[g], ys - 1), r1 = fetch(plane[g], ys);
+      nx[g] = fetch(plane[g], ys + 1);
+      ra[g] = finish(r0, plane[g], ys - 1);
+      rb[g] = finish(r1, plane[g], ys);
     }
     for (int i = 0; i < R; ++i) {
       const int oy = ys + i;
+      Raw cur[NP];
+#pragma unroll
+      for (int g = 0; g < NP; ++g) {
+        if (PLAIN2 && g == 1) continue;
+        cur[g] = nx[g];
+        nx[g] = fetch(plane[g], i + 1 < R ? oy + 2 : oy + 1);   // last trip: a row already cached, not a new one
+      }
 #pragma unroll
       for (int g = 0; g < NP; ++g) {
         if (PLAIN2 && g == 1) rb[g] = load_center(plane[g], oy);
-        else rc[g] = load_row(plane[g], oy + 1);
+        else rc[g] = finish(cur[g], plane[g], oy + 1);
       }
       emit(ra, rb, rc, oy);
 #pragma unroll
