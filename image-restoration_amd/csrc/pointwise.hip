@@ -129,6 +129,74 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
   }
 }
 
+// Single-pass form for C <= 4 * NCH: each wave keeps its channel slice (channels wave, wave + 4, ...) of
+// the 256 pixels in registers, so x is read from memory once, with all NCH 16-byte loads of a lane in flight
+// together; the two-pass statistics (mean, then variance about it) run on the registers.
+template <int KIND, int NCH>
+__global__ __launch_bounds__(256) void layernorm_regs_kernel(const float* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ y, long y_bs, int C, int P) {
+  __shared__ float part[2][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = (blockIdx.x * 64 + lane) * 4;
+  const int b = blockIdx.y;
+  const bool ok = p < P;   // P % 4 == 0: a lane is all in or all out
+  const float* __restrict__ xp = x + (long)b * x_bs + (ok ? p : 0);
+  float4 v[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = wave + 4 * i;
+    v[i] = *reinterpret_cast<const float4*>(xp + (long)min(c, C - 1) * P);   // clamped: no predicate around the load
+  }
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (wave + 4 * i < C) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+  *reinterpret_cast<float4*>(&part[0][wave][lane * 4]) = s;
+  __syncthreads();
+  float4 mu;
+  {
+    const float4 a0 = *reinterpret_cast<const float4*>(&part[0][0][lane * 4]), a1 = *reinterpret_cast<const float4*>(&part[0][1][lane * 4]);
+    const float4 a2 = *reinterpret_cast<const float4*>(&part[0][2][lane * 4]), a3 = *reinterpret_cast<const float4*>(&part[0][3][lane * 4]);
+    mu = make_float4((a0.x + a1.x + a2.x + a3.x) / (float)C, (a0.y + a1.y + a2.y + a3.y) / (float)C,
+                     (a0.z + a1.z + a2.z + a3.z) / (float)C, (a0.w + a1.w + a2.w + a3.w) / (float)C);
+  }
+  s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (wave + 4 * i < C) {
+      const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
+      s.x = fmaf(dx, dx, s.x); s.y = fmaf(dy, dy, s.y); s.z = fmaf(dz, dz, s.z); s.w = fmaf(dw, dw, s.w);
+    }
+  *reinterpret_cast<float4*>(&part[1][wave][lane * 4]) = s;
+  __syncthreads();
+  float4 rs;
+  {
+    const float4 a0 = *reinterpret_cast<const float4*>(&part[1][0][lane * 4]), a1 = *reinterpret_cast<const float4*>(&part[1][1][lane * 4]);
+    const float4 a2 = *reinterpret_cast<const float4*>(&part[1][2][lane * 4]), a3 = *reinterpret_cast<const float4*>(&part[1][3][lane * 4]);
+    rs = make_float4(1.0f / sqrtf((a0.x + a1.x + a2.x + a3.x) / (float)C + 1e-5f), 1.0f / sqrtf((a0.y + a1.y + a2.y + a3.y) / (float)C + 1e-5f),
+                     1.0f / sqrtf((a0.z + a1.z + a2.z + a3.z) / (float)C + 1e-5f), 1.0f / sqrtf((a0.w + a1.w + a2.w + a3.w) / (float)C + 1e-5f));
+  }
+  if (!ok) return;
+  float* __restrict__ yp = y + (long)b * y_bs + p;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = wave + 4 * i;
+    if (c >= C) break;
+    const float g = w[c];
+    float4 o;
+    if constexpr (KIND == 1) {
+      const float be = bias[c];
+      o = make_float4((v[i].x - mu.x) * rs.x * g + be, (v[i].y - mu.y) * rs.y * g + be, (v[i].z - mu.z) * rs.z * g + be,
+                      (v[i].w - mu.w) * rs.w * g + be);
+    } else {
+      o = make_float4(v[i].x * rs.x * g, v[i].y * rs.y * g, v[i].z * rs.z * g, v[i].w * rs.w * g);
+    }
+    *reinterpret_cast<float4*>(yp + (long)c * P) = o;
+  }
+}
+
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s) {
   JIRF_REQUIRE(kind == 1 || kind == 2, JIRF_EINVAL, "layernorm: kind %d", kind);
@@ -137,7 +205,18 @@ void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, 
   const bool vec = P % 4 == 0 && x.bs % 4 == 0 && y.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(y.p) & 15) == 0 && (long)B * P >= 256L * 1024;
   const dim3 block(256);
-  if (vec) {
+  if (vec && C <= 96) {
+    const dim3 grid((P + 255) / 256, B);
+#define JIRF_LN_REGS(N)                                                                                              \
+  do {                                                                                                               \
+    if (kind == 1) hipLaunchKernelGGL((layernorm_regs_kernel<1, N>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P); \
+    else hipLaunchKernelGGL((layernorm_regs_kernel<2, N>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P);       \
+  } while (0)
+    if (C <= 32) JIRF_LN_REGS(8);
+    else if (C <= 64) JIRF_LN_REGS(16);
+    else JIRF_LN_REGS(24);
+#undef JIRF_LN_REGS
+  } else if (vec) {
     const dim3 grid((P + 255) / 256, B);
     if (kind == 1)
       hipLaunchKernelGGL((layernorm_split_kernel<1, 4>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P);
