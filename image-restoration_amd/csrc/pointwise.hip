@@ -510,17 +510,45 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
     }
   };
   if constexpr (RFIX > 0) {
-    // fixed strip height: every input row of the strip is requested before the first output row is
-    // computed, so a wave keeps RFIX + 2 row loads in flight.  Used for the plain (one plane) form only:
-    // the gated forms, which read two planes a tensor half apart, measured slower this way (and with a
-    // one-row look-ahead) than with the rolling loop below
-    Row rows[RFIX + 2][NP];
+    // fixed strip height: every input row of the strip is requested (unpredicated, raw) before the first
+    // output row is computed, so a wave keeps (RFIX + 2) row loads per convolved plane in flight; the
+    // neighbour gathering happens row by row as the outputs are produced
+    constexpr bool PLAIN2F = MODE == 2 || MODE == 3;
+    Raw raws[RFIX + 2][NP];
 #pragma unroll
     for (int i = 0; i < RFIX + 2; ++i)
 #pragma unroll
-      for (int g = 0; g < NP; ++g) rows[i][g] = load_row(plane[g], ys - 1 + i);
+      for (int g = 0; g < NP; ++g) {
+        if (PLAIN2F && g == 1 && (i == 0 || i == RFIX + 1)) continue;   // the plain plane needs its centre rows only
+        raws[i][g] = fetch(plane[g], ys - 1 + i);
+      }
+    Row ra[NP], rb[NP], rc[NP];
 #pragma unroll
-    for (int i = 0; i < RFIX; ++i) emit(rows[i], rows[i + 1], rows[i + 2], ys + i);
+    for (int g = 0; g < NP; ++g) {
+      if (PLAIN2F && g == 1) continue;
+      ra[g] = finish(raws[0][g], plane[g], ys - 1);
+      rb[g] = finish(raws[1][g], plane[g], ys);
+    }
+#pragma unroll
+    for (int i = 0; i < RFIX; ++i) {
+#pragma unroll
+      for (int g = 0; g < NP; ++g) {
+        if (PLAIN2F && g == 1) {
+          const bool ok = x_ok && ys + i < H;
+#pragma unroll
+          for (int j = 0; j < PX; ++j) rb[g].v[1 + j] = ok ? raws[i + 1][g].m[j] : 0.f;
+        } else {
+          rc[g] = finish(raws[i + 2][g], plane[g], ys + i + 1);
+        }
+      }
+      emit(ra, rb, rc, ys + i);
+#pragma unroll
+      for (int g = 0; g < NP; ++g) {
+        if (PLAIN2F && g == 1) continue;
+        ra[g] = rb[g];
+        rb[g] = rc[g];
+      }
+    }
   } else {
     // the second plane of MODE 2 / 3 is multiplied in as it is: only its centre row is read, without
     // the neighbours
@@ -603,7 +631,7 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
     const dim3 g2((unsigned)((n_tasks + 3) / 4), B);
 #define JIRF_DW_ROWS(M, WM, WC)                                                                                      \
   do {                                                                                                               \
-    if (PX == 4 && R == 8 && M == 0)                                                                                 \
+    if (PX == 4 && R == 8)                                                                                                  \
       hipLaunchKernelGGL((dwconv3x3_rows_kernel<M, 4, 8>), g2, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,  \
                          lx_log2, R, tx, strips, n_tasks, WM, WC);                                                   \
     else if (PX == 4)                                                                                                \
