@@ -942,7 +942,8 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   Scope sc(intern_label("%s M%d K%d P%d", name, a.M, a.K, a.P), flops, bytes, s);
 
   // the RGB output convolutions: a handful of output rows would idle the matrix cores
-  if (loader == LD_CONV3 && !std::getenv("JIRF_GEMM_TILE") && try_launch_conv3x3_fewout(a, s)) return;
+  static const bool tile_forced = std::getenv("JIRF_GEMM_TILE") != nullptr;
+  if (loader == LD_CONV3 && !tile_forced && try_launch_conv3x3_fewout(a, s)) return;
 
   // Kernel choice, from per-shape measurements on MI355X (HINT / ASTv2 / AST shapes, B = 16):
   //  * activation-stationary kernel when LayerNorm rides on the load (it also replaces the
