@@ -1,0 +1,23 @@
+"""The alternative kernels behind the environment switches (read once per process) must pass the same
+golden cases as the default ones: each switch set runs tests/test_golden_gpu.py in a child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("switches", [
+    {"JIRF_WINATTN_VALU": "1", "JIRF_CROSSWIN_VALU": "1"},   # vector-ALU window attention kernels
+    {"JIRF_GEMM_NO_XS": "1"},                                 # every GEMM on the K-loop kernel
+    {"JIRF_GEMM_TILE": "3"},                                  # ... with 64 x 64 tiles, no few-output conv kernel
+    {"JIRF_GEMM_SPLIT_BF16": "1"},                            # split-bf16 activation-stationary GEMM
+])
+def test_golden_cases_with_switches(switches):
+    env = dict(os.environ, **switches)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_golden_gpu.py", "-x", "-q", "--timeout", "100",
+                        "--timeout-method", "thread"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=115)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
