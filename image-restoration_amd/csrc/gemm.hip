@@ -625,25 +625,50 @@ __global__ __launch_bounds__(256, 2) void gemm_xs3_kernel(const GemmArgs a, cons
   const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
 
   // ---- load the fp32 tile (rows past K and columns past P are zero) ---------------------------------
-  for (int s = tid; s < Kp * (BN / 4); s += 256) {
-    const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-    const int p = n0 + c4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < K && p < P) {
-      const float* __restrict__ src = xb + (long)k * P + p;
-      if constexpr (LOADER == LD_PLAIN) {
-        if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)k * P + p;
+  // (one unpredicated batch per thread, as in gemm_xs_kernel)
+  if constexpr (VEC) {
+    constexpr int LB = 8;
+    const int total = Kp * (BN / 4);
+    const float* __restrict__ xb2 = LOADER == LD_PLAIN && a.k_split > 0 ? a.x2.p + (long)b * a.x2.bs : xb;
+    for (int s0 = tid; s0 < total; s0 += 256 * LB) {
+      float4 v[LB];
+      bool ok[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const int s = s0 + u * 256;
+        const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+        const int p = n0 + c4;
+        ok[u] = s < total && k < K && p < P;
+        const int kc = min(k, K - 1);
+        const float* __restrict__ base = (LOADER == LD_PLAIN && kc < a.k_split) ? xb2 : xb;
+        v[u] = *reinterpret_cast<const float4*>(base + (long)kc * P + (p < P ? p : 0));
       }
-      if constexpr (VEC) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const int s = s0 + u * 256;
+        if (s < total) {
+          const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+          *reinterpret_cast<float4*>(&Xf[k * BN + c4]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  } else {
+    for (int s = tid; s < Kp * (BN / 4); s += 256) {
+      const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+      const int p = n0 + c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && p < P) {
+        const float* __restrict__ src = xb + (long)k * P + p;
+        if constexpr (LOADER == LD_PLAIN) {
+          if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)k * P + p;
+        }
         v.x = src[0];
         if (p + 1 < P) v.y = src[1];
         if (p + 2 < P) v.z = src[2];
         if (p + 3 < P) v.w = src[3];
       }
+      *reinterpret_cast<float4*>(&Xf[k * BN + c4]) = v;
     }
-    *reinterpret_cast<float4*>(&Xf[k * BN + c4]) = v;
   }
   __syncthreads();
   const int col = tid % BN, part = tid / BN;
