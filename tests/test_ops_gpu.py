@@ -118,3 +118,18 @@ def test_dwconv3x3(gate, B, C, H, W, bias):
     bd = None if b is None else dev(b)
     call("jirf_op_dwconv3x3", ptr(xd), ptr(wd), ptr(bd), ptr(y), B, C, H, W, gate, stream())
     assert max_abs(y.cpu(), ref) < 5e-6
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("C", [20, 32, 48, 64, 96, 100])
+def test_layernorm_large_plane(kind, C):
+    """Planes of >= 256k pixels take the float4 kernels: the register-resident single-pass form for C <= 96
+    (three channel-count variants) and the three-pass form above it."""
+    B, P = 2, 131072 + 256
+    x = (RNG.standard_normal((B, C, P)) * 2 + 0.5).astype(np.float32)
+    lw, lb = (1 + 0.1 * rnd(C)), 0.1 * rnd(C)
+    n = oc.channel_layernorm(torch.from_numpy(x).reshape(B, C, P, 1), torch.from_numpy(lw), torch.from_numpy(lb), kind == 1)
+    xd, lwd, lbd = dev(x), dev(lw), dev(lb)
+    y = torch.empty(B, C, P, device="cuda")
+    call("jirf_op_layernorm", ptr(xd), ptr(lwd), ptr(lbd), ptr(y), B, C, P, kind, stream())
+    assert max_abs(y.cpu(), n.reshape(B, C, P)) < 2e-5
