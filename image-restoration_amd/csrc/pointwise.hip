@@ -756,10 +756,12 @@ bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
                         al(a.x.p, a.x.bs) && al(a.y.p, a.y.bs) && (a.epi != EP_RESID || al(a.r.p, a.r.bs));
   if (!shape_ok) return false;
   const int H = a.H, W = a.W;
-  const int R = a.M <= 4 ? 4 : a.M == 8 ? 2 : 1;
   int lx_log2 = 0;
   while ((1 << lx_log2) < 64 && (4 << lx_log2) < W) ++lx_log2;
   const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
+  // rows per lane: as many as the accumulators allow, fewer while that leaves under 512 waves in the grid
+  int R = a.M <= 4 ? 4 : a.M == 8 ? 2 : 1;
+  while (R > 1 && (long)((W + 4 * LX - 1) / (4 * LX)) * ((H + RW * R - 1) / (RW * R)) * a.B < 512) R >>= 1;
   const int tiles_x = (W + 4 * LX - 1) / (4 * LX), strips = (H + RW * R - 1) / (RW * R);
   const int n_tasks = tiles_x * strips;
   const dim3 grid((unsigned)((n_tasks + 3) / 4), a.B), block(256);
@@ -767,14 +769,24 @@ bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
 #define JIRF_FEWOUT(CO, RR)                                                                            \
   hipLaunchKernelGGL((conv3x3_fewout_kernel<CO, RR>), grid, block, 0, s, a.x.p, a.x.bs, a.wt, a.Mpad, a.bias, res, \
                      a.r.bs, a.y.p, a.y.bs, a.Cin, H, W, lx_log2, tiles_x, n_tasks)
+#define JIRF_FEWOUT_R(CO)              \
+  do {                                 \
+    if (R == 4) JIRF_FEWOUT(CO, 4);    \
+    else if (R == 2) JIRF_FEWOUT(CO, 2); \
+    else JIRF_FEWOUT(CO, 1);           \
+  } while (0)
   switch (a.M) {
-    case 1: JIRF_FEWOUT(1, 4); break;
-    case 2: JIRF_FEWOUT(2, 4); break;
-    case 3: JIRF_FEWOUT(3, 4); break;
-    case 4: JIRF_FEWOUT(4, 4); break;
-    case 8: JIRF_FEWOUT(8, 2); break;
+    case 1: JIRF_FEWOUT_R(1); break;
+    case 2: JIRF_FEWOUT_R(2); break;
+    case 3: JIRF_FEWOUT_R(3); break;
+    case 4: JIRF_FEWOUT_R(4); break;
+    case 8:
+      if (R == 2) JIRF_FEWOUT(8, 2);
+      else JIRF_FEWOUT(8, 1);
+      break;
     default: JIRF_FEWOUT(16, 1); break;
   }
+#undef JIRF_FEWOUT_R
 #undef JIRF_FEWOUT
   JIRF_HIP_CHECK(hipGetLastError());
   return true;
