@@ -76,7 +76,13 @@ class JirfModule:
         return self
 
     def cuda(self, device: Optional[int] = None):
-        if device is not None and device != self._device:
+        """`.cuda()` with no argument binds to torch's current device, like nn.Module.cuda."""
+        if device is None and torch is not None and torch.cuda.is_available():
+            device = torch.cuda.current_device()
+        if device is not None and not isinstance(device, int):
+            device = getattr(device, "index", None) if not isinstance(device, str) else torch.device(device).index
+            device = 0 if device is None else device
+        if device is not None and int(device) != self._device:
             self._device = int(device)
             self._drop_native()
         return self
@@ -144,6 +150,9 @@ class JirfModule:
         oc = self._out_channels(c)
         if torch is not None and isinstance(x, torch.Tensor):
             if x.is_cuda:
+                if x.device.index != self._device:
+                    raise ValueError(f"{self.ARCH}: input lives on cuda:{x.device.index} but the network is bound "
+                                     f"to cuda:{self._device} (move it with .cuda({x.device.index}))")
                 xc = x.detach().contiguous().float()
                 y = torch.empty((b, oc, h, w), dtype=torch.float32, device=x.device)
                 stream = torch.cuda.current_stream(x.device).cuda_stream

@@ -207,8 +207,8 @@ class HintNet final : public Net {
     pB_ = B; pH_ = H; pW_ = W; pmode_ = mode;
     stage_in = in_; stage_out = outb_; io_in_ch = inp_ch_; io_out_ch = out_ch_;
     ensure_cache_store(mode == JIRF_BATCH_COUPLED ? 1 : B);
-    // a cache carried from a call with another batch layout cannot be continued
-    if (cache_valid_ && cache_g_ != (mode == JIRF_BATCH_COUPLED ? 1 : B)) cache_valid_ = false;
+    // a cache carried from a call with another batch layout cannot be continued: it is kept, and the
+    // next forward reports JIRF_ESTATE until the caller resets or replaces it (never dropped silently)
     return arena_.bytes;
   }
 

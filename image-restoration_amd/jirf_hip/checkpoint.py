@@ -123,16 +123,32 @@ def select_params(load_net: Dict, arch_name: str, param_key: Optional[str] = "pa
 
 
 def load_network(net, load_path: str, strict: bool = True, param_key: Optional[str] = "params"):
-    """`BaseModel.load_network` (base_model.py:228-258) for a network_g of this package."""
+    """`BaseModel.load_network` (base_model.py:228-258) for a network_g of this package.  As there, key
+    mismatches are reported (`_print_different_keys_loading`, base_model.py:195-226) and the keys both
+    sides know are loaded: the reference calls `net.load_state_dict(load_net)` without a strict flag, and
+    `strict` only decides whether entries of a different size are set aside.  A parameter that no file
+    ever supplied still fails, by name, when the network is first used."""
     logger.info("Loading %s model from %s.", net.__class__.__name__, load_path)
     state = select_params(load(load_path), net.__class__.__name__, param_key)
+    shapes = net.named_parameter_shapes()
+    canon = getattr(net, "_canonical", lambda k: k)
+    have = {canon(k) for k in state} - {None}
+    missing = sorted(set(shapes) - have)
+    extra = sorted(k for k in state if canon(k) is not None and canon(k) not in shapes)
+    if missing or extra:
+        logger.warning("Current net - loaded net:")
+        for k in missing:
+            logger.warning("  %s", k)
+        logger.warning("Loaded net - current net:")
+        for k in extra:
+            logger.warning("  %s", k)
     if not strict:     # base_model.py:221-226: entries whose size differs are set aside, not loaded
-        shapes = net.named_parameter_shapes()
         for k in list(state):
-            if k in shapes and int(np.prod(np.shape(state[k]))) != int(np.prod(shapes[k])):
-                logger.warning("Size different, ignore [%s]: crt_net: %s; load_net: %s", k, shapes[k], np.shape(state[k]))
+            ck = canon(k)
+            if ck in shapes and int(np.prod(np.shape(state[k]))) != int(np.prod(shapes[ck])):
+                logger.warning("Size different, ignore [%s]: crt_net: %s; load_net: %s", k, shapes[ck], np.shape(state[k]))
                 state[k + ".ignore"] = state.pop(k)
-    net.load_state_dict(state, strict=strict)
+    net.load_state_dict(state, strict=False)
     return net
 
 

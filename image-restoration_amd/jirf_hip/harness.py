@@ -149,20 +149,55 @@ def to_uint8_image(restored: torch.Tensor, h: int, w: int) -> torch.Tensor:
 
 
 def restore_image(net, img: torch.Tensor, factor: int = 8, crop_size: int = None, overlap_size: int = None,
-                  tile_batch: int = 16, square_multiple: int = None) -> torch.Tensor:
+                  tile_batch: int = 16, square_multiple: int = None, carry_cache: bool = False) -> torch.Tensor:
     """One image through a test script's loop body (test_rain100L.py:147-190): pad, restore (whole
     image, or `crop_size` tiles with `overlap_size` overlap as the FPro / GoPro branches do),
     unpad, clamp.  img: [B,3,h,w] float32 on the GPU; returns [B,3,h,w].  With `square_multiple` the image
-    is padded to the enclosing square instead (`pad_to_square`, for AST)."""
+    is padded to the enclosing square instead (`pad_to_square`, for AST).
+
+    Tiles are independent B = 1 calls in the scripts, so tile batches always run with per-image batch
+    semantics (no statistic of one tile reaches another), whatever `net.batch_mode` says, and the result
+    does not depend on `tile_batch`.  For a network that carries state between calls (HINT's `qv_cache`,
+    hint_arch.py:511,660-696) the tiled branch has two modes (the whole-image branch is one plain call
+    and leaves the state to the network, which carries it like the reference module):
+      carry_cache=False  every tile starts cold (`qv_cache = None`), so tiles can be batched and sharded;
+                         the cache is None again on return;
+      carry_cache=True   the script's literal loop (Motion_Deblurring/test_GoPro.py:142-171): tiles go
+                         through one at a time in list order and each starts from the cache the previous
+                         call left (the first from whatever the network holds on entry); the last tile's
+                         cache stays in the network.  Needs a single image (B = 1)."""
     x = _dev(img)
     h, w = x.shape[2], x.shape[3]
     xp = pad_to_square(x, square_multiple) if square_multiple else pad_to_factor(x, factor)
+    stateful = hasattr(net, "qv_cache")
+    if carry_cache and not stateful:
+        raise ValueError("carry_cache needs a network with a qv_cache (HINT)")
     if crop_size is None:
-        restored = net(xp)
+        restored = net(xp)      # one call: the network's own call-to-call state applies, as in the scripts
     else:
         split, starts = splitimage(xp, crop_size, overlap_size)
         tiles = split.stacked
-        outs = [net(tiles[i:i + tile_batch]) for i in range(0, tiles.shape[0], tile_batch)]
+        had_mode = getattr(net, "batch_mode", None)
+        try:
+            if carry_cache:
+                if x.shape[0] != 1:
+                    raise ValueError("carry_cache replays the scripts' B = 1 loop: pass one image")
+                if had_mode is not None:
+                    net.batch_mode = "coupled"          # a literal B = 1 call; the cache stays [1,C,C]
+                outs = [net(tiles[i:i + 1]) for i in range(tiles.shape[0])]
+            else:
+                if had_mode is not None:
+                    net.batch_mode = "per_image"
+                outs = []
+                for i in range(0, tiles.shape[0], tile_batch):
+                    if stateful:
+                        net.qv_cache = None
+                    outs.append(net(tiles[i:i + tile_batch]))
+                if stateful:
+                    net.qv_cache = None
+        finally:
+            if had_mode is not None:
+                net.batch_mode = had_mode
         done = TileList()
         done.stacked = torch.cat(outs, dim=0)
         restored = mergeimage(done, starts, crop_size, tuple(xp.shape))

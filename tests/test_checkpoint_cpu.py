@@ -113,8 +113,35 @@ def test_load_network_into_the_hint_class(tmp_path):
     ck.save({"params": on_disk}, str(p))
     net = ck.load_network(HINT(**cfg), str(p), strict=True, param_key="params_ema")
     out = net.state_dict()
-    assert set(out) == set(sd) and all(np.array_equal(out[k], np.asarray(sd[k])) for k in sd)
+    assert set(out) == set(sd) | {"qv_cache"} and all(np.array_equal(out[k], np.asarray(sd[k])) for k in sd)
     q = tmp_path / "copy.jth"
     ck.save_network(net, str(q))
     again = ck.load(str(q))["params"]
     assert list(again) == list(out)
+    # the reference's loader and every HINT test script run `del checkpoint["params"]["qv_cache"]` without a
+    # guard (base_model.py:243-244, Deraining/test_rain100L.py:121-122): a file this package writes must hold it
+    assert again["qv_cache"].shape == (1, 32, 32) and again["qv_cache"].dtype == np.float32
+    del again["qv_cache"]
+    assert set(again) == set(sd)
+
+
+def test_load_network_reports_key_mismatches_and_loads_the_rest(tmp_path, caplog):
+    """base_model.py:257-258: differing keys are logged, then `net.load_state_dict(load_net)` runs without a
+    strict flag - an extra or missing entry does not abort the load."""
+    from basicsr.models.archs.hint_arch import HINT
+    cfg = dict(synthetic.default_config("HINT"))
+    cfg.update(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    sd = dict(synthetic.make_state("HINT", cfg, seed=2))
+    dropped = "output.weight"
+    kept = {k: v for k, v in sd.items() if k != dropped}
+    kept["some_buffer_the_net_does_not_have"] = np.zeros(3, np.float32)
+    kept["qv_cache"] = np.zeros((1, 32, 32), np.float32)
+    p = tmp_path / "partial.jth"
+    ck.save({"params": kept}, str(p))
+    import logging
+    with caplog.at_level(logging.WARNING, logger="basicsr"):
+        net = ck.load_network(HINT(**cfg), str(p), strict=True)
+    text = caplog.text
+    assert dropped in text and "some_buffer_the_net_does_not_have" in text
+    out = net.state_dict()
+    assert dropped not in out and "patch_embed.proj.weight" in out

@@ -87,10 +87,20 @@ def test_attention_core(mode, B, C, P, cache_c, mod_gain):
                                                    tap=lambda n, t: taps.__setitem__(n, t))
         gap = _min_gap(taps["a.mean_similarity"])
         got = perm[g].cpu().numpy()
+        assert sorted(got.tolist()) == list(range(C)), "device channel order is not a permutation"
         if gap > RANK_MARGIN:
             assert np.array_equal(got, order.numpy()), f"channel order differs (oracle min gap {gap:.2e})"
-        else:
-            pytest.skip(f"oracle similarity gap {gap:.2e} below margin; order undefined")
+        elif not np.array_equal(got, order.numpy()):
+            # a near tie in the oracle's similarity means: the order itself is undefined there, but every
+            # other output is a function of the order, so evaluate the oracle on the device's order and
+            # keep asserting (the swapped channels must be the near-tied ones)
+            sim = taps["a.mean_similarity"].numpy()
+            moved = np.nonzero(got != order.numpy())[0]
+            span = np.abs(sim[got[moved]] - sim[order.numpy()[moved]]).max()
+            assert span < 10 * RANK_MARGIN, f"order differs beyond a near tie (similarity span {span:.2e})"
+            print(f"[attention_core C={C} P={P}] near tie (gap {gap:.2e}): oracle re-evaluated on the device order")
+            ro, rt, ratt, rcache, _ = ho.hmha_core(p, "a", q[sl], k[sl], v[sl], cg, sw,
+                                                   forced_order=torch.from_numpy(got.astype(np.int64)))
         assert max_abs(out[sl].cpu(), ro) < 2e-5 * max(1.0, float(ro.abs().max()))
         assert max_abs(s_out[sl].cpu(), ro + rt) < 2e-5 * max(1.0, float(ro.abs().max()))
         a_gpu = att[sl].cpu()
