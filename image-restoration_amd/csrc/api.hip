@@ -1,5 +1,6 @@
 // extern "C" surface of libjirf_hip.so (declared in include/jirf_hip.h).  Every entry point
 // catches jirf::Failure and returns its code; nothing throws across the ABI.
+#include <atomic>
 #include <cstring>
 #include <new>
 
@@ -286,6 +287,81 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
     g.mu = mu; g.rstd = rstd; g.lnw = ln_w; g.lnb = ln_kind == 1 ? ln_b : nullptr; g.ln_center = ln_kind == 1;
     launch_gemm(g, LD_LN, s);
     JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    return JIRF_OK;
+  });
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------------------
+// jirf_op_ln_conv1x1 keeps two things in device memory besides its input and output: the weights in
+// the GEMM's K-major packing and, for Cin > 256, the per-pixel LayerNorm statistics.  Here both live in
+// one file-scope device array, so the call needs no hipMalloc.  Every GPU the library runs on holds its
+// own copy of the array at its own address; that address is looked up once per device.
+static __device__ __align__(256) float scratch[JIRF_STATIC_MAX_PACKED_WEIGHT_FLOATS + 2 * JIRF_STATIC_MAX_PIXELS];
+
+namespace {
+constexpr size_t STATIC_W_FLOATS = JIRF_STATIC_MAX_PACKED_WEIGHT_FLOATS;
+constexpr size_t STATIC_PIXELS = JIRF_STATIC_MAX_PIXELS;
+
+constexpr int STATIC_MAX_DEVICES = 64;
+std::atomic<float*> g_scratch_ptr[STATIC_MAX_DEVICES];
+
+// Device address of `scratch` on the current device (the array's name is only a host-side handle).
+float* static_scratch() {
+  int dev = -1;
+  JIRF_HIP_CHECK(hipGetDevice(&dev));
+  JIRF_REQUIRE(dev >= 0 && dev < STATIC_MAX_DEVICES, JIRF_EINVAL, "static scratch: device %d out of range", dev);
+  float* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* sym = nullptr;
+    JIRF_HIP_CHECK(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+    JIRF_REQUIRE(sym != nullptr, JIRF_EHIP, "static scratch: no device address on device %d", dev);
+    p = static_cast<float*>(sym);
+    g_scratch_ptr[dev].store(p, std::memory_order_release);   // every thread finds the same address
+  }
+  return p;
+}
+
+// w [M][K] (reference layout, device) -> wt [Kp][Mp] K-major, zero padded: every element of the packed
+// image is written, so nothing of an earlier, larger call survives in the padding.
+__global__ __launch_bounds__(256) void pack_wt_1x1_kernel(const float* __restrict__ w, float* __restrict__ wt, int M,
+                                                          int K, int Mp, int Kp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Kp * Mp) return;
+  const int k = i / Mp, o = i - k * Mp;
+  wt[i] = (k < K && o < M) ? w[(long)o * K + k] : 0.f;
+}
+}  // namespace
+
+int jirf_op_ln_conv1x1_static(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
+                              const float* w_dev, float* y, int B, int Cin, int Cout, int P, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && ln_w && w_dev && y && B > 0 && Cin > 0 && Cout > 0 && P > 0, JIRF_EINVAL,
+                 "ln_conv1x1_static: bad arguments");
+    JIRF_REQUIRE(ln_kind == 1 || ln_kind == 2, JIRF_EINVAL, "ln_conv1x1_static: ln_kind %d", ln_kind);
+    JIRF_REQUIRE(ln_kind == 2 || ln_b, JIRF_EINVAL, "ln_conv1x1_static: WithBias needs ln_b");
+    const long Kp = (Cin + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+    const long Mp = (Cout + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+    JIRF_REQUIRE((size_t)(Kp * Mp) <= STATIC_W_FLOATS, JIRF_EINVAL,
+                 "ln_conv1x1_static: packed weights of Cin=%d Cout=%d take %ld floats, the static scratch holds %zu "
+                 "(use jirf_op_ln_conv1x1)", Cin, Cout, Kp * Mp, STATIC_W_FLOATS);
+    JIRF_REQUIRE((size_t)B * (size_t)P <= STATIC_PIXELS, JIRF_EINVAL,
+                 "ln_conv1x1_static: B*P = %zu pixels, the static scratch holds statistics for %zu "
+                 "(use jirf_op_ln_conv1x1)", (size_t)B * (size_t)P, STATIC_PIXELS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* base = static_scratch();
+    float* wt = base;
+    float* mu = base + STATIC_W_FLOATS;
+    float* rstd = mu + (size_t)B * P;
+    hipLaunchKernelGGL(pack_wt_1x1_kernel, dim3((unsigned)((Kp * Mp + 255) / 256)), dim3(256), 0, s, w_dev, wt, Cout, Cin,
+                       (int)Mp, (int)Kp);
+    JIRF_HIP_CHECK(hipGetLastError());
+    const TV xv = tv(const_cast<float*>(x), (long)Cin * P);
+    if (!gemm_ln_inline(Cin)) launch_ln_stats(xv, mu, rstd, B, Cin, P, s);
+    GemmArgs g{};
+    g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = (int)Mp; g.wt = wt;
+    g.x = xv; g.y = tv(y, (long)Cout * P); g.imgs_per_group = 1; g.epi = EP_STORE;
+    g.mu = mu; g.rstd = rstd; g.lnw = ln_w; g.lnb = ln_kind == 1 ? ln_b : nullptr; g.ln_center = ln_kind == 1;
+    launch_gemm(g, LD_LN, s);
     return JIRF_OK;
   });
 }

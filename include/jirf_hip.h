@@ -137,6 +137,20 @@ int jirf_op_conv1x1(const float* x, const float* w_host, const float* bias_host,
  * call.  ln_kind 1 = WithBias, 2 = BiasFree (hint_arch.py:98-145). */
 int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
                        const float* w_host, float* y, int B, int Cin, int Cout, int P, void* stream);
+/* No counterpart in the reference.  jirf_op_ln_conv1x1 for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the packed
+ * weights and, for Cin > 256, the per-pixel LayerNorm statistics live in a static device array of
+ * (JIRF_STATIC_MAX_PACKED_WEIGHT_FLOATS + 2 * JIRF_STATIC_MAX_PIXELS) * 4 bytes = 10 MiB that every GPU
+ * the library runs on holds until the process ends; the call makes no hipMalloc / hipFree, copies
+ * nothing from the host and does not synchronise (asynchronous on `stream`).  Differences from
+ * jirf_op_ln_conv1x1: w_dev [Cout,Cin] is a DEVICE array in the reference layout (packed by a kernel
+ * inside the call).  Limits: ceil16(Cin) * ceil128(Cout) <= JIRF_STATIC_MAX_PACKED_WEIGHT_FLOATS and
+ * B * P <= JIRF_STATIC_MAX_PIXELS, otherwise JIRF_EINVAL and nothing is launched.  All calls on one
+ * GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+#define JIRF_STATIC_MAX_PACKED_WEIGHT_FLOATS (512 * 1024)
+#define JIRF_STATIC_MAX_PIXELS (1024 * 1024)
+int jirf_op_ln_conv1x1_static(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
+                              const float* w_dev, float* y, int B, int Cin, int Cout, int P, void* stream);
 /* Dense 3x3, stride 1, zero pad 1 (hint_arch.py:441-448,459-466,479-486,648-655).
  * w_host [Cout,Cin,3,3].  mode 0: plain; 1: followed by pixel-unshuffle(2)
  * (hint_arch.py:35-56); 2: followed by pixel-shuffle(2); res (NULL or [B,Cout,H,W]) is

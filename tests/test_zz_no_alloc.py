@@ -1,0 +1,55 @@
+"""The entry point that allocates nothing (jirf_op_ln_conv1x1_static) against the entry point it is a
+variant of (jirf_op_ln_conv1x1), through the C ABI.  Both run the same kernels on the same packed
+weights, so the outputs must be bit-identical; the static one keeps the packed weights and the
+LayerNorm statistics in the library's per-GPU device array, which keeps its contents between calls —
+hence the call pairs below, the second of each with a smaller problem."""
+import numpy as np
+import pytest
+import torch
+
+import jirf_hip
+from tests.gpu_util import call, dev, hptr, ptr, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(kind, B, C, Cout, P, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((B, C, P)) * 2 + 0.5).astype(np.float32)
+    lw = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    lb = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    w = (rng.standard_normal((Cout, C)) * C ** -0.5).astype(np.float32)
+    xd, lwd, lbd, wd = dev(x), dev(lw), dev(lb), dev(w)
+    want = torch.full((B, Cout, P), float("nan"), device="cuda")
+    got = torch.full((B, Cout, P), float("nan"), device="cuda")
+    call("jirf_op_ln_conv1x1", ptr(xd), ptr(lwd), ptr(lbd), kind, hptr(w), ptr(want), B, C, Cout, P, stream())
+    call("jirf_op_ln_conv1x1_static", ptr(xd), ptr(lwd), ptr(lbd), kind, ptr(wd), ptr(got), B, C, Cout, P, stream())
+    return got.cpu().numpy(), want.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("first,second", [
+    # Cin > 256: statistics pass + K-loop GEMM, mu / rstd in the static array
+    ((2, 384, 1020, 4096), (1, 320, 254, 130)),
+    # Cin <= 256: statistics inside the GEMM tile; only the packed weights use the array
+    ((2, 96, 510, 4096), (1, 48, 144, 1000)),
+    # a large pixel count first, then a small one (stale statistics beyond B * P must not matter)
+    ((1, 288, 96, 256 * 256), (3, 272, 40, 77)),
+])
+def test_static_entry_point_matches_and_survives_a_smaller_second_call(kind, first, second):
+    for i, (B, C, Cout, P) in enumerate((first, second)):
+        got, want = _both(kind, B, C, Cout, P, seed=7 + i)
+        assert np.isfinite(want).all()
+        assert np.array_equal(got, want), f"call {i}: max |diff| = {np.abs(got - want).max()}"
+
+
+def test_static_entry_point_rejects_sizes_beyond_its_array():
+    L = jirf_hip.lib()
+    x = torch.zeros(8, device="cuda")
+    # packed weights: ceil16(1024) * ceil128(1024) = 1 Mi floats > 512 Ki
+    rc = L.jirf_op_ln_conv1x1_static(ptr(x), ptr(x), ptr(x), 1, ptr(x), ptr(x), 1, 1024, 1024, 64, stream())
+    assert rc == -1 and "static scratch holds" in jirf_hip.last_error()
+    # statistics: B * P beyond 1 Mi pixels
+    rc = L.jirf_op_ln_conv1x1_static(ptr(x), ptr(x), ptr(x), 1, ptr(x), ptr(x), 5, 48, 48, 256 * 1024, stream())
+    assert rc == -1 and "pixels" in jirf_hip.last_error()
+    torch.cuda.synchronize()
