@@ -117,6 +117,91 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, int b, const f32x1
   }
 }
 
+// Epilogue of TNW accumulator tiles whose columns are interleaved: lane l31 owns the TNW adjacent pixels
+// col0 .. col0 + TNW - 1 (tile j holds pixel col0 + j), so one row of the lane's results is one 8- or
+// 16-byte store and everything the epilogue reads comes in the same width.  A wave then issues 16 stores
+// per group of tiles instead of 16 per tile: a wave may have 64 memory operations outstanding, and with
+// one store per element the epilogue of a 32 x 128 block ran at the rate that limit and the write latency
+// allow (~4 us), during which the wave issues no MFMA.  FULL: all 32 rows < M and every column < P;
+// otherwise rows and column groups are predicated (loads from clamped, always valid addresses).
+// P % TNW == 0 and 4 * TNW byte alignment of every row are the caller's responsibility.
+template <int EPI, int TNW, bool FULL>
+__device__ __forceinline__ void store_rows_v(const GemmArgs& a, int b, const f32x16* acc, int rbase, int half,
+                                             int col0, const float* bias_r) {
+  typedef float VT __attribute__((ext_vector_type(TNW)));
+  const int M = a.M, P = a.P;
+  const bool col_ok = FULL || col0 < P;
+  const unsigned voff = (unsigned)(4 * half) * (unsigned)P + (unsigned)col0;
+  auto urow = [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); };
+  auto lane_ok = [&](int r) { return FULL || (col_ok && urow(r) + 4 * half < M); };
+  auto row_ptr = [&](auto* base, int r) { return base + (long)(FULL ? urow(r) : min(urow(r), M - 1)) * P; };
+  float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
+  if constexpr (EPI == EP_SHUFFLE) {   // scattered by construction: element stores
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+      const int col = col0 + j;
+      const int py = col / a.W, px = col - py * a.W;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!lane_ok(r)) continue;
+        const int row = urow(r) + 4 * half;
+        const int oy = 2 * py + ((row >> 1) & 1), ox = 2 * px + (row & 1);
+        yb[(long)(row >> 2) * (4L * P) + (long)oy * (2 * a.W) + ox] = acc[j][r] + bias_r[r];
+      }
+    }
+    return;
+  }
+  VT aux[16];
+  if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL) {
+    const float* __restrict__ rp = a.r.p + (long)b * a.r.bs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aux[r] = *reinterpret_cast<const VT*>(row_ptr(rp, r) + (lane_ok(r) ? voff : 0u));
+  }
+  if constexpr (EPI == EP_AV_INTRA) {
+    const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
+    const int col = FULL ? col0 : (col_ok ? col0 : 0);
+    const float* __restrict__ qp = a.q.p + (long)b * a.q.bs + col;
+    const float* __restrict__ kp = a.k.p + (long)b * a.k.bs + col;
+    int src[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = urow(r) + 4 * half;
+      src[r] = perm[FULL ? row : min(row, M - 1)];
+    }
+    VT qv[16], kv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      qv[r] = *reinterpret_cast<const VT*>(qp + (long)src[r] * P);
+      kv[r] = *reinterpret_cast<const VT*>(kp + (long)src[r] * P);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aux[r] = qv[r] * a.rq[(long)b * M + src[r]] + kv[r] * a.rk[(long)b * M + src[r]];
+  }
+  float* __restrict__ y2b = nullptr;
+  if constexpr (EPI == EP_AV_INTRA) y2b = a.y2.p + (long)b * a.y2.bs;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (!lane_ok(r)) continue;
+    VT v;
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) v[j] = acc[j][r] + bias_r[r];
+    if constexpr (EPI == EP_RESID) {
+      v += aux[r];
+    } else if constexpr (EPI == EP_GELU_MUL) {
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) v[j] = gelu_erf(v[j]) * aux[r][j];
+    } else if constexpr (EPI == EP_GELU) {
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) v[j] = gelu_erf(v[j]);
+    } else if constexpr (EPI == EP_LEAKY) {
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) v[j] = v[j] > 0.f ? v[j] : 0.01f * v[j];
+    }
+    *reinterpret_cast<VT*>(row_ptr(yb, r) + voff) = v;
+    if constexpr (EPI == EP_AV_INTRA) *reinterpret_cast<VT*>(row_ptr(y2b, r) + voff) = v + aux[r];
+  }
+}
+
 template <int MODE>
 __device__ __forceinline__ void load_bias16(const GemmArgs& a_in, int b, int rbase, int half, float* bias_r) {
   struct { const float* bias; int M; } a{a_in.bias ? a_in.bias + (long)b * a_in.bias_bs : nullptr, a_in.M};
@@ -388,10 +473,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
 // ------------------------------------------------------------------------------------------------
 constexpr int XS_ABATCH = 8;  // k-steps of A fragments fetched ahead
 
+// Diagnostic build only (-DJIRF_XS_PROBE, never the shipped library): shader-clock stamps at the phase
+// boundaries of every wave of gemm_xs_kernel, read back through jirf_debug_xs_probe.
+#ifdef JIRF_XS_PROBE
+constexpr int XS_PROBE_SLOTS = 48, XS_PROBE_WGS = 8192;
+__device__ unsigned long long g_xs_probe[XS_PROBE_WGS * 4 * XS_PROBE_SLOTS];
+#define XS_STAMP(slot)                                                                                       \
+  do {                                                                                                       \
+    if (blockIdx.x < XS_PROBE_WGS && blockIdx.y == 0 && lane == 0 && (slot) < XS_PROBE_SLOTS)                 \
+      g_xs_probe[((long)blockIdx.x * 4 + wave) * XS_PROBE_SLOTS + (slot)] = __builtin_amdgcn_s_memtime();     \
+  } while (0)
+#else
+#define XS_STAMP(slot) do {} while (0)
+#endif
+#define XS_PROBE_SLOTS_LAST 47
+
 template <int BN, int TNW, int LOADER, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float xs_smem[];
   constexpr int NG = BN / (32 * TNW);  // pixel groups a wave can own
+  constexpr bool IL = VEC && TNW > 1;  // interleaved pixel columns (needs P % 4 == 0 and 16-byte aligned rows)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.x / tiles_n;
@@ -407,6 +508,11 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   const int* __restrict__ kidx = nullptr;
   if constexpr (LOADER == LD_GATHER) kidx = a.kidx + (long)(b / a.imgs_per_group) * K;
 
+  XS_STAMP(0);
+#ifdef JIRF_XS_PROBE
+  if (blockIdx.x < XS_PROBE_WGS && blockIdx.y == 0 && lane == 0)
+    g_xs_probe[((long)blockIdx.x * 4 + wave) * XS_PROBE_SLOTS + 1] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);   // HW_ID, XCC_ID
+#endif
   // ---- load the tile --------------------------------------------------------------------------
   // In batches of XS_LB 16-byte loads per thread, all issued before the first LDS store: a loop of
   // load - wait - store keeps one load in flight per thread and leaves the tile load latency-bound.
@@ -414,95 +520,179 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   // since a predicated load makes the compiler wait at the join.
   float* __restrict__ st_g = st_rs + BN;             // [Kp] LayerNorm weight (LD_LN)
   float* __restrict__ st_b = st_g + Kp;              // [Kp] LayerNorm bias
-  if constexpr (LOADER == LD_LN) {
-    for (int k = tid; k < K; k += 256) {
-      st_g[k] = a.lnw[k];
-      st_b[k] = a.lnb ? a.lnb[k] : 0.f;
-    }
-  }
-  if constexpr (VEC) {
-    constexpr int XS_LB = 12;
-    const int total = Kp * (BN / 4);
-    const float* __restrict__ xb2 = LOADER == LD_PLAIN && a.k_split > 0 ? a.x2.p + (long)b * a.x2.bs : xb;
-    for (int s0 = tid; s0 < total; s0 += 256 * XS_LB) {
-      float4 v[XS_LB];
-      bool ok[XS_LB];
+  if constexpr (LOADER == LD_LN && VEC) {
+    // LayerNorm in registers.  A wave owns CW groups of four pixels; a lane holds every RW-th channel of
+    // its group, so all channels of a pixel live in one wave: mean and variance (two passes over the
+    // registers, as the reference's mean / var(unbiased=False)) are lane-exchange sums, and the tile
+    // reaches LDS once, already normalised.  One barrier (before the waves read each other's columns).
+    constexpr int CW = BN / 16;            // groups of four pixels per wave: 8 (BN = 128) or 4 (BN = 64)
+    constexpr int RW = 64 / CW;            // channels one load instruction covers: 8 or 16
+    constexpr int NSMAX = 16;              // register slots: Kp <= 16 RW is checked at launch
+    const int cg = wave * CW + (lane % CW), r0 = lane / CW;
+    const int ns = Kp / RW;                // Kp is a multiple of 16
+    const int p = n0 + cg * 4;
+    const bool col_ok = p < P;             // P % 4 == 0 here: the four pixels of a group stand or fall together
+    const float* __restrict__ src = xb + (col_ok ? p : 0);
+    const bool has_b = a.lnb != nullptr;
+    float4 v[NSMAX];
+    float g[NSMAX], be[NSMAX];
 #pragma unroll
-      for (int u = 0; u < XS_LB; ++u) {
-        const int s = s0 + u * 256;
+    for (int h = 0; h < NSMAX / 2; ++h) {
+      if (2 * h < ns) {                    // wave-uniform: whole pairs of loads are skipped, none is predicated
+#pragma unroll
+        for (int u = 2 * h; u < 2 * h + 2; ++u) {
+          const int k = min(r0 + RW * u, K - 1);
+#ifdef JIRF_XS_PROBE
+          if (a.k_split & 1) v[u] = make_float4(0.01f * lane, 0.1f * u, 1.f, -0.3f * k);   // ablation: no tile load
+          else
+#endif
+          v[u] = *reinterpret_cast<const float4*>(src + (long)k * P);
+          g[u] = a.lnw[k];
+          be[u] = has_b ? a.lnb[k] : 0.f;
+        }
+      }
+    }
+    auto lane_sum = [&](float4& t) {
+#pragma unroll
+      for (int m = CW; m < 64; m <<= 1) {
+        t.x += __shfl_xor(t.x, m);
+        t.y += __shfl_xor(t.y, m);
+        t.z += __shfl_xor(t.z, m);
+        t.w += __shfl_xor(t.w, m);
+      }
+    };
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NSMAX; ++u) {
+      if (u < ns) {
+        if (r0 + RW * u >= K) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);   // a padding row (clamped load)
+        sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w;
+      }
+    }
+    XS_STAMP(2);
+    lane_sum(sum);
+    const float inv_k = 1.0f / (float)K;
+    const float4 mu = make_float4(sum.x * inv_k, sum.y * inv_k, sum.z * inv_k, sum.w * inv_k);
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NSMAX; ++u) {
+      if (u < ns && r0 + RW * u < K) {
+        const float dx = v[u].x - mu.x, dy = v[u].y - mu.y, dz = v[u].z - mu.z, dw = v[u].w - mu.w;
+        m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
+      }
+    }
+    lane_sum(m2);
+    const float4 rs = make_float4(1.0f / sqrtf(m2.x * inv_k + 1e-5f), 1.0f / sqrtf(m2.y * inv_k + 1e-5f),
+                                  1.0f / sqrtf(m2.z * inv_k + 1e-5f), 1.0f / sqrtf(m2.w * inv_k + 1e-5f));
+    const float4 mc = a.ln_center ? mu : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NSMAX; ++u) {
+      if (u < ns) {
+        const int k = r0 + RW * u;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && col_ok) {             // rows past K and columns past the image stay zero
+          o.x = (v[u].x - mc.x) * rs.x * g[u] + be[u];
+          o.y = (v[u].y - mc.y) * rs.y * g[u] + be[u];
+          o.z = (v[u].z - mc.z) * rs.z * g[u] + be[u];
+          o.w = (v[u].w - mc.w) * rs.w * g[u] + be[u];
+        }
+        *reinterpret_cast<float4*>(&Xs[k * BN + cg * 4]) = o;
+      }
+    }
+    __syncthreads();
+  } else {
+    if constexpr (LOADER == LD_LN) {
+      for (int k = tid; k < K; k += 256) {
+        st_g[k] = a.lnw[k];
+        st_b[k] = a.lnb ? a.lnb[k] : 0.f;
+      }
+    }
+    if constexpr (VEC) {
+      constexpr int XS_LB = 12;
+      const int total = Kp * (BN / 4);
+      const float* __restrict__ xb2 = LOADER == LD_PLAIN && a.k_split > 0 ? a.x2.p + (long)b * a.x2.bs : xb;
+      for (int s0 = tid; s0 < total; s0 += 256 * XS_LB) {
+        float4 v[XS_LB];
+        bool ok[XS_LB];
+  #pragma unroll
+        for (int u = 0; u < XS_LB; ++u) {
+          const int s = s0 + u * 256;
+          const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+          const int p = n0 + c4;
+          ok[u] = s < total && k < K && p < P;
+          const int kc = min(k, K - 1);
+          int row = kc;
+          if constexpr (LOADER == LD_GATHER) row = kidx[kc];
+          const float* __restrict__ base = (LOADER == LD_PLAIN && kc < a.k_split) ? xb2 : xb;
+          v[u] = *reinterpret_cast<const float4*>(base + (long)row * P + (p < P ? p : 0));
+        }
+  #pragma unroll
+        for (int u = 0; u < XS_LB; ++u) {
+          const int s = s0 + u * 256;
+          if (s < total) {
+            const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+            *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+    } else {
+      for (int s = tid; s < Kp * (BN / 4); s += 256) {
         const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
         const int p = n0 + c4;
-        ok[u] = s < total && k < K && p < P;
-        const int kc = min(k, K - 1);
-        int row = kc;
-        if constexpr (LOADER == LD_GATHER) row = kidx[kc];
-        const float* __restrict__ base = (LOADER == LD_PLAIN && kc < a.k_split) ? xb2 : xb;
-        v[u] = *reinterpret_cast<const float4*>(base + (long)row * P + (p < P ? p : 0));
-      }
-#pragma unroll
-      for (int u = 0; u < XS_LB; ++u) {
-        const int s = s0 + u * 256;
-        if (s < total) {
-          const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-          *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && p < P) {
+          int row = k;
+          if constexpr (LOADER == LD_GATHER) row = kidx[k];
+          const float* __restrict__ src = xb + (long)row * P + p;
+          if constexpr (LOADER == LD_PLAIN) {
+            if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)row * P + p;
+          }
+          v.x = src[0];
+          if (p + 1 < P) v.y = src[1];
+          if (p + 2 < P) v.z = src[2];
+          if (p + 3 < P) v.w = src[3];
         }
+        *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
       }
-    }
-  } else {
-    for (int s = tid; s < Kp * (BN / 4); s += 256) {
-      const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-      const int p = n0 + c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K && p < P) {
-        int row = k;
-        if constexpr (LOADER == LD_GATHER) row = kidx[k];
-        const float* __restrict__ src = xb + (long)row * P + p;
-        if constexpr (LOADER == LD_PLAIN) {
-          if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)row * P + p;
-        }
-        v.x = src[0];
-        if (p + 1 < P) v.y = src[1];
-        if (p + 2 < P) v.z = src[2];
-        if (p + 3 < P) v.w = src[3];
-      }
-      *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
-    }
-  }
-  __syncthreads();
-  if constexpr (LOADER == LD_LN) {
-    // per-pixel mean and population variance over the K channels (two passes, as the reference's
-    // mean / var(unbiased=False)); columns past the image stay zero
-    if (tid < BN) {
-      float sum = 0.f;
-      for (int k = 0; k < K; ++k) sum += Xs[k * BN + tid];
-      const float mu = sum / (float)K;
-      float var = 0.f;
-      for (int k = 0; k < K; ++k) {
-        const float d = Xs[k * BN + tid] - mu;
-        var = fmaf(d, d, var);
-      }
-      st_mu[tid] = a.ln_center ? mu : 0.f;
-      st_rs[tid] = n0 + tid < P ? 1.0f / sqrtf(var / (float)K + 1e-5f) : 0.f;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int s = tid; s < K * (BN / 4); s += 256) {
-      const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-      const float g = st_g[k];
-      const float be = st_b[k];
-      float4 v = *reinterpret_cast<float4*>(&Xs[k * BN + c4]);
-      const float4 mu = *reinterpret_cast<const float4*>(&st_mu[c4]);
-      const float4 rs = *reinterpret_cast<const float4*>(&st_rs[c4]);
-      const int p = n0 + c4;
-      v.x = p < P ? (v.x - mu.x) * rs.x * g + be : 0.f;
-      v.y = p + 1 < P ? (v.y - mu.y) * rs.y * g + be : 0.f;
-      v.z = p + 2 < P ? (v.z - mu.z) * rs.z * g + be : 0.f;
-      v.w = p + 3 < P ? (v.w - mu.w) * rs.w * g + be : 0.f;
-      *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
+    XS_STAMP(2);
+    if constexpr (LOADER == LD_LN) {
+      // per-pixel mean and population variance over the K channels (two passes, as the reference's
+      // mean / var(unbiased=False)); columns past the image stay zero
+      if (tid < BN) {
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += Xs[k * BN + tid];
+        const float mu = sum / (float)K;
+        float var = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float d = Xs[k * BN + tid] - mu;
+          var = fmaf(d, d, var);
+        }
+        st_mu[tid] = a.ln_center ? mu : 0.f;
+        st_rs[tid] = n0 + tid < P ? 1.0f / sqrtf(var / (float)K + 1e-5f) : 0.f;
+      }
+      __syncthreads();
+  #pragma unroll 4
+      for (int s = tid; s < K * (BN / 4); s += 256) {
+        const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
+        const float g = st_g[k];
+        const float be = st_b[k];
+        float4 v = *reinterpret_cast<float4*>(&Xs[k * BN + c4]);
+        const float4 mu = *reinterpret_cast<const float4*>(&st_mu[c4]);
+        const float4 rs = *reinterpret_cast<const float4*>(&st_rs[c4]);
+        const int p = n0 + c4;
+        v.x = p < P ? (v.x - mu.x) * rs.x * g + be : 0.f;
+        v.y = p + 1 < P ? (v.y - mu.y) * rs.y * g + be : 0.f;
+        v.z = p + 2 < P ? (v.z - mu.z) * rs.z * g + be : 0.f;
+        v.w = p + 3 < P ? (v.w - mu.w) * rs.w * g + be : 0.f;
+        *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
+  XS_STAMP(3);
   // ---- output tiles -----------------------------------------------------------------------------
   const float* __restrict__ wt = a.wt + (long)b * a.wt_bs;
   const int n_mt = (M + 31) >> 5;
@@ -537,10 +727,18 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const float* __restrict__ ap = a_ptr(item);
     const float* __restrict__ ap_next = a_ptr(item + 4 < n_items ? item + 4 : item);
-    const float* __restrict__ bp = Xs + half * BN + col_w + l31;
+    // IL: the lane's TNW pixels are adjacent (one LDS read per k-step feeds all TNW MFMAs, and the
+    // epilogue stores them as one vector); otherwise tile j holds pixel j * 32 + l31
+    const float* __restrict__ bp = Xs + half * BN + col_w + (IL ? TNW * l31 : l31);
     for (int s0 = 0; s0 < nsteps; s0 += XS_ABATCH) {
       const bool last = s0 + XS_ABATCH >= nsteps;
       const float* __restrict__ src = last ? ap_next : ap + (long)(2 * (s0 + XS_ABATCH)) * a.Mpad;
+#ifdef JIRF_XS_PROBE
+      if (a.k_split & 2) {                                                               // ablation: no weight loads
+#pragma unroll
+        for (int i = 0; i < XS_ABATCH; ++i) a_nxt[i] = a_cur[i] * 0.999f;
+      } else
+#endif
 #pragma unroll
       for (int i = 0; i < XS_ABATCH; ++i) a_nxt[i] = src[(long)(2 * i) * a.Mpad];
       // keep the next batch's fetches in front of this batch's MFMAs: the scheduler otherwise sinks
@@ -548,18 +746,41 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < XS_ABATCH; ++i) {
+        if constexpr (IL) {
+          typedef float VT __attribute__((ext_vector_type(TNW)));
+          const VT bq = *reinterpret_cast<const VT*>(&bp[(2 * (s0 + i)) * BN]);
 #pragma unroll
-        for (int j = 0; j < TNW; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], bp[(2 * (s0 + i)) * BN + j * 32], acc[j], 0, 0, 0);
+          for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], bq[j], acc[j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < TNW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], bp[(2 * (s0 + i)) * BN + j * 32], acc[j], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = a_nxt[i];
     }
+    XS_STAMP(4 + 2 * ((item - item_lo) >> 2));
     float bias_r[16];
     auto store_all = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
       constexpr int ST = FULL ? ST_FULL : ST_CLAMP;
       load_bias16<ST>(a, b, m0, half, bias_r);
+      if constexpr (IL) {
+        const int col0 = n0 + col_w + TNW * l31;
+        if constexpr (LOADER == LD_GATHER) {
+          store_rows_v<EP_AV_INTRA, TNW, FULL>(a, b, acc, m0, half, col0, bias_r);
+        } else if constexpr (LOADER == LD_LN) {
+          store_rows_v<EP_STORE, TNW, FULL>(a, b, acc, m0, half, col0, bias_r);
+        } else {
+          if (epi == EP_RESID) store_rows_v<EP_RESID, TNW, FULL>(a, b, acc, m0, half, col0, bias_r);
+          else if (epi == EP_GELU_MUL) store_rows_v<EP_GELU_MUL, TNW, FULL>(a, b, acc, m0, half, col0, bias_r);
+          else if (epi == EP_GELU) store_rows_v<EP_GELU, TNW, FULL>(a, b, acc, m0, half, col0, bias_r);
+          else if (epi == EP_SHUFFLE) store_rows_v<EP_SHUFFLE, TNW, FULL>(a, b, acc, m0, half, col0, bias_r);
+          else store_rows_v<EP_STORE, TNW, FULL>(a, b, acc, m0, half, col0, bias_r);
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < TNW; ++j) {
         const int col = n0 + col_w + j * 32 + l31;
@@ -577,9 +798,14 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
         }
       }
     };
+#ifdef JIRF_XS_PROBE
+    if ((a.k_split & 4) && a.epi != 12345) {} else                                       // ablation: no stores
+#endif
     if (m0 + 32 <= M && n0 + BN <= P) store_all(std::true_type{});
     else store_all(std::false_type{});
+    XS_STAMP(5 + 2 * ((item - item_lo) >> 2));
   }
+  XS_STAMP(XS_PROBE_SLOTS_LAST);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -784,6 +1010,12 @@ __global__ __launch_bounds__(256, 2) void gemm_xs3_kernel(const GemmArgs a, cons
   }
 }
 
+#ifdef JIRF_XS_PROBE
+extern "C" int jirf_debug_xs_probe(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xs_probe), sizeof(unsigned long long) * XS_PROBE_WGS * 4 * XS_PROBE_SLOTS);
+}
+#endif
+
 bool gemm_split_bf16_enabled() {
   static const bool on = std::getenv("JIRF_GEMM_SPLIT_BF16") && std::atoi(std::getenv("JIRF_GEMM_SPLIT_BF16")) != 0;
   return on;
@@ -851,10 +1083,19 @@ static bool xs_enabled() {
 bool gemm_ln_inline(int K) { return K <= 256 && xs_enabled(); }
 
 template <int BN, int TNW>
-static void launch_xs(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
+static void launch_xs(const GemmArgs& a_in, int loader, bool vec, hipStream_t s) {
+#ifdef JIRF_XS_PROBE
+  GemmArgs a_abl = a_in;
+  if (loader == LD_LN && std::getenv("JIRF_XS_ABL")) a_abl.k_split = std::atoi(std::getenv("JIRF_XS_ABL"));
+  const GemmArgs& a = a_abl;
+#else
+  const GemmArgs& a = a_in;
+#endif
   const int tiles_n = (a.P + BN - 1) / BN;
   const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
   const size_t smem = ((size_t)Kp * BN + 2 * BN + 2 * Kp) * sizeof(float);
+  // the register-resident LayerNorm holds a lane's share of the tile in 16 slots
+  JIRF_REQUIRE(loader != LD_LN || Kp <= 16 * (1024 / BN), JIRF_EINVAL, "launch_xs: K=%d does not fit %d-pixel tiles", a.K, BN);
   // fewer workgroups than twice the CUs: split the output-row tiles over gridDim.y (at least 4 per part)
   const int n_mt = (a.M + 31) / 32;
   int msplit = 1;
@@ -986,8 +1227,14 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
     // 128-pixel tiles need K <= 128 (LDS) and enough of them: an underfilled grid does better with 64-pixel
     // tiles (half the tile load per workgroup) than with more row splits of the wide ones
     const long wide_tiles = (long)((a.P + 127) / 128) * a.B;
-    if (a.K <= 128 && wide_tiles >= 512) launch_xs_bn<128>(a, loader, vec, s);
-    else launch_xs_bn<64>(a, loader, vec, s);
+    // the activation-stationary kernel's vector form also stores (and reads its epilogue operands) in
+    // 16-byte pieces
+    auto al16 = [](const TV& t) { return t.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(t.p) & 15) == 0; };
+    const bool vec_xs = vec && (a.epi == EP_SHUFFLE || al16(a.y)) &&
+                        ((a.epi != EP_RESID && a.epi != EP_GELU_MUL) || al16(a.r)) &&
+                        (a.epi != EP_AV_INTRA || (al16(a.y2) && al16(a.q) && al16(a.k)));
+    if (a.K <= 128 && wide_tiles >= 512) launch_xs_bn<128>(a, loader, vec_xs, s);
+    else launch_xs_bn<64>(a, loader, vec_xs, s);
     return;
   }
   if (loader == LD_LN)
