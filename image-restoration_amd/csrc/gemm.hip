@@ -134,7 +134,12 @@ __device__ __forceinline__ void store_rows_v(const GemmArgs& a, int b, const f32
   const unsigned voff = (unsigned)(4 * half) * (unsigned)P + (unsigned)col0;
   auto urow = [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); };
   auto lane_ok = [&](int r) { return FULL || (col_ok && urow(r) + 4 * half < M); };
+#ifdef JIRF_XS_PROBE
+  // ablation: every 32-row block stores over the tensor's first 32 rows (same instructions, cache-resident lines)
+  auto row_ptr = [&](auto* base, int r) { return base + (long)((a.k_split & 8) ? (urow(r) & 31) : FULL ? urow(r) : min(urow(r), M - 1)) * P; };
+#else
   auto row_ptr = [&](auto* base, int r) { return base + (long)(FULL ? urow(r) : min(urow(r), M - 1)) * P; };
+#endif
   float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
   if constexpr (EPI == EP_SHUFFLE) {   // scattered by construction: element stores
 #pragma unroll
@@ -151,54 +156,62 @@ __device__ __forceinline__ void store_rows_v(const GemmArgs& a, int b, const f32
     }
     return;
   }
-  VT aux[16];
-  if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL) {
-    const float* __restrict__ rp = a.r.p + (long)b * a.r.bs;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) aux[r] = *reinterpret_cast<const VT*>(row_ptr(rp, r) + (lane_ok(r) ? voff : 0u));
-  }
-  if constexpr (EPI == EP_AV_INTRA) {
-    const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
-    const int col = FULL ? col0 : (col_ok ? col0 : 0);
-    const float* __restrict__ qp = a.q.p + (long)b * a.q.bs + col;
-    const float* __restrict__ kp = a.k.p + (long)b * a.k.bs + col;
-    int src[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = urow(r) + 4 * half;
-      src[r] = perm[FULL ? row : min(row, M - 1)];
-    }
-    VT qv[16], kv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      qv[r] = *reinterpret_cast<const VT*>(qp + (long)src[r] * P);
-      kv[r] = *reinterpret_cast<const VT*>(kp + (long)src[r] * P);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) aux[r] = qv[r] * a.rq[(long)b * M + src[r]] + kv[r] * a.rk[(long)b * M + src[r]];
-  }
+  // rows go in chunks of RC: everything a chunk reads is requested before its first store, and the
+  // operands of one chunk (not of all 16 rows) are what the epilogue adds to the register count
+  constexpr int RC = (TNW >= 4 || EPI == EP_AV_INTRA) ? 4 : 8;
   float* __restrict__ y2b = nullptr;
   if constexpr (EPI == EP_AV_INTRA) y2b = a.y2.p + (long)b * a.y2.bs;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    if (!lane_ok(r)) continue;
-    VT v;
+  for (int c0 = 0; c0 < 16; c0 += RC) {
+    VT aux[RC];
+    if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL) {
+      const float* __restrict__ rp = a.r.p + (long)b * a.r.bs;
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) v[j] = acc[j][r] + bias_r[r];
-    if constexpr (EPI == EP_RESID) {
-      v += aux[r];
-    } else if constexpr (EPI == EP_GELU_MUL) {
-#pragma unroll
-      for (int j = 0; j < TNW; ++j) v[j] = gelu_erf(v[j]) * aux[r][j];
-    } else if constexpr (EPI == EP_GELU) {
-#pragma unroll
-      for (int j = 0; j < TNW; ++j) v[j] = gelu_erf(v[j]);
-    } else if constexpr (EPI == EP_LEAKY) {
-#pragma unroll
-      for (int j = 0; j < TNW; ++j) v[j] = v[j] > 0.f ? v[j] : 0.01f * v[j];
+      for (int i = 0; i < RC; ++i)
+        aux[i] = *reinterpret_cast<const VT*>(row_ptr(rp, c0 + i) + (lane_ok(c0 + i) ? voff : 0u));
     }
-    *reinterpret_cast<VT*>(row_ptr(yb, r) + voff) = v;
-    if constexpr (EPI == EP_AV_INTRA) *reinterpret_cast<VT*>(row_ptr(y2b, r) + voff) = v + aux[r];
+    if constexpr (EPI == EP_AV_INTRA) {
+      const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
+      const int col = FULL ? col0 : (col_ok ? col0 : 0);
+      const float* __restrict__ qp = a.q.p + (long)b * a.q.bs + col;
+      const float* __restrict__ kp = a.k.p + (long)b * a.k.bs + col;
+      int src[RC];
+#pragma unroll
+      for (int i = 0; i < RC; ++i) {
+        const int row = urow(c0 + i) + 4 * half;
+        src[i] = perm[FULL ? row : min(row, M - 1)];
+      }
+      VT qv[RC], kv[RC];
+#pragma unroll
+      for (int i = 0; i < RC; ++i) {
+        qv[i] = *reinterpret_cast<const VT*>(qp + (long)src[i] * P);
+        kv[i] = *reinterpret_cast<const VT*>(kp + (long)src[i] * P);
+      }
+#pragma unroll
+      for (int i = 0; i < RC; ++i) aux[i] = qv[i] * a.rq[(long)b * M + src[i]] + kv[i] * a.rk[(long)b * M + src[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+      const int r = c0 + i;
+      if (!lane_ok(r)) continue;
+      VT v;
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) v[j] = acc[j][r] + bias_r[r];
+      if constexpr (EPI == EP_RESID) {
+        v += aux[i];
+      } else if constexpr (EPI == EP_GELU_MUL) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) v[j] = gelu_erf(v[j]) * aux[i][j];
+      } else if constexpr (EPI == EP_GELU) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) v[j] = gelu_erf(v[j]);
+      } else if constexpr (EPI == EP_LEAKY) {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) v[j] = v[j] > 0.f ? v[j] : 0.01f * v[j];
+      }
+      *reinterpret_cast<VT*>(row_ptr(yb, r) + voff) = v;
+      if constexpr (EPI == EP_AV_INTRA) *reinterpret_cast<VT*>(row_ptr(y2b, r) + voff) = v + aux[i];
+    }
   }
 }
 
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
         if (p + 3 < P) v.w = src[3];
       }
       if constexpr (LOADER == LD_LN) {
-        const float g = a.lnw[k];
+        const float g = a.lnw ? a.lnw[k] : 1.f;
         const float be = a.lnb ? a.lnb[k] : 0.f;
         const float4 mu = ln_mu[i], rs = ln_rs[i];
         if (a.ln_center) {
@@ -508,6 +521,9 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   const int* __restrict__ kidx = nullptr;
   if constexpr (LOADER == LD_GATHER) kidx = a.kidx + (long)(b / a.imgs_per_group) * K;
 
+#ifdef JIRF_XS_PROBE
+  if (a.k_split & 16) __builtin_amdgcn_s_setprio(3);
+#endif
   XS_STAMP(0);
 #ifdef JIRF_XS_PROBE
   if (blockIdx.x < XS_PROBE_WGS && blockIdx.y == 0 && lane == 0)
@@ -520,6 +536,13 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   // since a predicated load makes the compiler wait at the join.
   float* __restrict__ st_g = st_rs + BN;             // [Kp] LayerNorm weight (LD_LN)
   float* __restrict__ st_b = st_g + Kp;              // [Kp] LayerNorm bias
+  // The output bias waits in LDS for the epilogues (rows past M as zeros): a vector-memory load there
+  // would sit in the same in-order counter as the weight-fragment window and make the epilogue wait for it.
+  float* __restrict__ st_bias = st_b + Kp;           // [ceil32(M)] when a.bias
+  if (a.bias) {
+    const float* __restrict__ bsrc = a.bias + (long)b * a.bias_bs;
+    for (int m = tid; m < ((M + 31) & ~31); m += 256) st_bias[m] = m < M ? bsrc[m] : 0.f;
+  }
   if constexpr (LOADER == LD_LN && VEC) {
     // LayerNorm in registers.  A wave owns CW groups of four pixels; a lane holds every RW-th channel of
     // its group, so all channels of a pixel live in one wave: mean and variance (two passes over the
@@ -533,7 +556,9 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
     const int p = n0 + cg * 4;
     const bool col_ok = p < P;             // P % 4 == 0 here: the four pixels of a group stand or fall together
     const float* __restrict__ src = xb + (col_ok ? p : 0);
-    const bool has_b = a.lnb != nullptr;
+    // affine == false: the caller has folded the LayerNorm weight into the GEMM weights and its bias into
+    // the output bias (pack_upload_ln_1x1), and the tile is only normalised here
+    const bool affine = a.lnw != nullptr, has_b = a.lnb != nullptr;
     float4 v[NSMAX];
     float g[NSMAX], be[NSMAX];
 #pragma unroll
@@ -547,11 +572,14 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
           else
 #endif
           v[u] = *reinterpret_cast<const float4*>(src + (long)k * P);
-          g[u] = a.lnw[k];
-          be[u] = has_b ? a.lnb[k] : 0.f;
+          if (affine) {
+            g[u] = a.lnw[k];
+            be[u] = has_b ? a.lnb[k] : 0.f;
+          }
         }
       }
     }
+    XS_STAMP(40);
     auto lane_sum = [&](float4& t) {
 #pragma unroll
       for (int m = CW; m < 64; m <<= 1) {
@@ -571,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
     }
     XS_STAMP(2);
     lane_sum(sum);
+    XS_STAMP(42);
     const float inv_k = 1.0f / (float)K;
     const float4 mu = make_float4(sum.x * inv_k, sum.y * inv_k, sum.z * inv_k, sum.w * inv_k);
     float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -582,6 +611,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
       }
     }
     lane_sum(m2);
+    XS_STAMP(43);
     const float4 rs = make_float4(1.0f / sqrtf(m2.x * inv_k + 1e-5f), 1.0f / sqrtf(m2.y * inv_k + 1e-5f),
                                   1.0f / sqrtf(m2.z * inv_k + 1e-5f), 1.0f / sqrtf(m2.w * inv_k + 1e-5f));
     const float4 mc = a.ln_center ? mu : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -591,19 +621,26 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
         const int k = r0 + RW * u;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K && col_ok) {             // rows past K and columns past the image stay zero
-          o.x = (v[u].x - mc.x) * rs.x * g[u] + be[u];
-          o.y = (v[u].y - mc.y) * rs.y * g[u] + be[u];
-          o.z = (v[u].z - mc.z) * rs.z * g[u] + be[u];
-          o.w = (v[u].w - mc.w) * rs.w * g[u] + be[u];
+          o.x = (v[u].x - mc.x) * rs.x;
+          o.y = (v[u].y - mc.y) * rs.y;
+          o.z = (v[u].z - mc.z) * rs.z;
+          o.w = (v[u].w - mc.w) * rs.w;
+          if (affine) {
+            o.x = o.x * g[u] + be[u];
+            o.y = o.y * g[u] + be[u];
+            o.z = o.z * g[u] + be[u];
+            o.w = o.w * g[u] + be[u];
+          }
         }
         *reinterpret_cast<float4*>(&Xs[k * BN + cg * 4]) = o;
       }
     }
+    XS_STAMP(44);
     __syncthreads();
   } else {
     if constexpr (LOADER == LD_LN) {
       for (int k = tid; k < K; k += 256) {
-        st_g[k] = a.lnw[k];
+        st_g[k] = a.lnw ? a.lnw[k] : 1.f;
         st_b[k] = a.lnb ? a.lnb[k] : 0.f;
       }
     }
@@ -702,19 +739,38 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   const int n_items = min(((int)blockIdx.y + 1) * mt_per, n_mt) * NG;
   const int nsteps = Kp >> 1;
   const int epi = a.epi;
-  // A-fragment address of an item: rows past Mpad do not exist in the packed weights, so the
-  // column is clamped (results of such rows are never stored)
-  auto a_ptr = [&](int item) {
-    const int m0 = (item / NG) * 32;
-    return wt + (long)half * a.Mpad + min(m0 + l31, a.Mpad - 1);
-  };
-  // nsteps is a multiple of XS_ABATCH (K is padded to 16): every load below is unconditional, and
-  // the batch fetched during an item's last batch already belongs to the wave's next item
-  float a_cur[XS_ABATCH], a_nxt[XS_ABATCH];
-  if (item_lo + wave < n_items) {
-    const float* __restrict__ ap0 = a_ptr(item_lo + wave);
+  // ---- the MFMA loop: a rolling window instead of batches ------------------------------------------
+  // A wave alone on its SIMD must keep the matrix pipe fed (the workgroups sharing the SIMD spend most of
+  // their life in load / LayerNorm / store phases).  So nothing waits at a batch boundary: the weight
+  // fragment of k-step s + 8 is requested into the register that k-step s has just used, the LDS fragment
+  // of k-step s + 2 likewise, and both windows run on into the wave's next item.  Weights are read through
+  // a buffer descriptor: the row advances in the scalar offset, the lane part is one register per item, and
+  // rows past Mpad do not exist in the packed weights, so the column is clamped (such rows are never stored).
+  typedef float BV __attribute__((ext_vector_type(TNW)));
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, Kp * a.Mpad * 4, 0x00020000);
+  const int row2 = 2 * a.Mpad * 4;                      // bytes per k-step (two weight rows)
+  auto a_voff = [&](int item) { return (half * a.Mpad + min((item / NG) * 32 + l31, a.Mpad - 1)) * 4; };
+  auto b_ptr = [&](int item) { return Xs + half * BN + (item % NG) * TNW * 32 + (IL ? TNW * l31 : l31); };
+  auto load_b = [&](const float* __restrict__ q) {
+    BV v;
+    if constexpr (IL) {
+      v = *reinterpret_cast<const BV*>(q);
+    } else {
 #pragma unroll
-    for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = ap0[(long)(2 * i) * a.Mpad];
+      for (int j = 0; j < TNW; ++j) v[j] = q[j * 32];
+    }
+    return v;
+  };
+  float a_cur[XS_ABATCH];
+  BV b_cur[2];
+  if (item_lo + wave < n_items) {
+    const int v0 = a_voff(item_lo + wave);
+#pragma unroll
+    for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, v0, i * row2, 0));
+    const float* __restrict__ b0 = b_ptr(item_lo + wave);
+    b_cur[0] = load_b(b0);
+    b_cur[1] = load_b(b0 + 2 * BN);
   }
   for (int item = item_lo + wave; item < n_items; item += 4) {
     const int mt = item / NG, ng = item - mt * NG;
@@ -725,47 +781,47 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
     for (int j = 0; j < TNW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const float* __restrict__ ap = a_ptr(item);
-    const float* __restrict__ ap_next = a_ptr(item + 4 < n_items ? item + 4 : item);
-    // IL: the lane's TNW pixels are adjacent (one LDS read per k-step feeds all TNW MFMAs, and the
-    // epilogue stores them as one vector); otherwise tile j holds pixel j * 32 + l31
-    const float* __restrict__ bp = Xs + half * BN + col_w + (IL ? TNW * l31 : l31);
+    const int item_n = item + 4 < n_items ? item + 4 : item;
+    const int av = a_voff(item), av_n = a_voff(item_n);
+    const float* __restrict__ bp = b_ptr(item);
+    const float* __restrict__ bp_n = b_ptr(item_n);
+#ifdef JIRF_XS_PROBE
+    if (a.k_split & 48) __builtin_amdgcn_s_setprio(0);
+#endif
     for (int s0 = 0; s0 < nsteps; s0 += XS_ABATCH) {
       const bool last = s0 + XS_ABATCH >= nsteps;
-      const float* __restrict__ src = last ? ap_next : ap + (long)(2 * (s0 + XS_ABATCH)) * a.Mpad;
-#ifdef JIRF_XS_PROBE
-      if (a.k_split & 2) {                                                               // ablation: no weight loads
-#pragma unroll
-        for (int i = 0; i < XS_ABATCH; ++i) a_nxt[i] = a_cur[i] * 0.999f;
-      } else
-#endif
-#pragma unroll
-      for (int i = 0; i < XS_ABATCH; ++i) a_nxt[i] = src[(long)(2 * i) * a.Mpad];
-      // keep the next batch's fetches in front of this batch's MFMAs: the scheduler otherwise sinks
-      // them to the end of the batch and their L2 latency is exposed at the top of the next one
-      __builtin_amdgcn_sched_barrier(0);
+      const int a_v = last ? av_n : av;                               // window k-steps s0 + 8 ...
+      const int a_s = last ? 0 : (s0 + XS_ABATCH) * row2;
+      const float* __restrict__ b_c = bp + (2 * s0) * BN;
+      const float* __restrict__ b_n = last ? bp_n : bp + (2 * (s0 + XS_ABATCH)) * BN;
 #pragma unroll
       for (int i = 0; i < XS_ABATCH; ++i) {
-        if constexpr (IL) {
-          typedef float VT __attribute__((ext_vector_type(TNW)));
-          const VT bq = *reinterpret_cast<const VT*>(&bp[(2 * (s0 + i)) * BN]);
 #pragma unroll
-          for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], bq[j], acc[j], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int j = 0; j < TNW; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], bp[(2 * (s0 + i)) * BN + j * 32], acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < TNW; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[i & 1][j], acc[j], 0, 0, 0);
+        a_cur[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, a_v, a_s + i * row2, 0));
+        b_cur[i & 1] = load_b(i + 2 < XS_ABATCH ? b_c + (2 * (i + 2)) * BN : b_n + (2 * (i + 2 - XS_ABATCH)) * BN);
+        // one k-step = TNW MFMAs, one weight fetch, one LDS fetch, in that order
+        __builtin_amdgcn_sched_group_barrier(0x8, TNW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, IL ? 1 : TNW, 0);
       }
-#pragma unroll
-      for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = a_nxt[i];
     }
+#ifdef JIRF_XS_PROBE
+    if (a.k_split & 32) __builtin_amdgcn_s_setprio(3);
+#endif
     XS_STAMP(4 + 2 * ((item - item_lo) >> 2));
     float bias_r[16];
     auto store_all = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
       constexpr int ST = FULL ? ST_FULL : ST_CLAMP;
-      load_bias16<ST>(a, b, m0, half, bias_r);
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[r] = st_bias[m0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
+      }
       if constexpr (IL) {
         const int col0 = n0 + col_w + TNW * l31;
         if constexpr (LOADER == LD_GATHER) {
@@ -934,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs3_kernel(const GemmArgs a, cons
         float v = Xf[k * BN + col];
         if constexpr (LOADER == LD_LN) {
           const int kc = min(k, K - 1);
-          const float gg = a.lnw[kc];
+          const float gg = a.lnw ? a.lnw[kc] : 1.f;
           const float be = a.lnb ? a.lnb[kc] : 0.f;
           v = (k < K && col_ok) ? (v - mu) * rs * gg + be : 0.f;
         }
@@ -1093,7 +1149,7 @@ static void launch_xs(const GemmArgs& a_in, int loader, bool vec, hipStream_t s)
 #endif
   const int tiles_n = (a.P + BN - 1) / BN;
   const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
-  const size_t smem = ((size_t)Kp * BN + 2 * BN + 2 * Kp) * sizeof(float);
+  const size_t smem = ((size_t)Kp * BN + 2 * BN + 2 * Kp + (a.bias ? (a.M + 31) / 32 * 32 : 0)) * sizeof(float);
   // the register-resident LayerNorm holds a lane's share of the tile in 16 slots
   JIRF_REQUIRE(loader != LD_LN || Kp <= 16 * (1024 / BN), JIRF_EINVAL, "launch_xs: K=%d does not fit %d-pixel tiles", a.K, BN);
   // fewer workgroups than twice the CUs: split the output-row tiles over gridDim.y (at least 4 per part)

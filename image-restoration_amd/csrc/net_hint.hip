@@ -96,6 +96,11 @@ class HintNet final : public Net {
     auto conv1 = [&](const std::string& k, int M, int K) {
       return pack_upload_1x1(pool_, host(k + ".weight").data(), bias_ ? host(k + ".bias").data() : nullptr, M, K);
     };
+    auto conv1_ln = [&](const std::string& k, const std::string& ln, int M, int K) {  // LayerNorm folded in
+      return pack_upload_ln_1x1(pool_, host(k + ".weight").data(), bias_ ? host(k + ".bias").data() : nullptr,
+                                host(ln + ".body.weight").data(),
+                                with_bias_ln_ ? host(ln + ".body.bias").data() : nullptr, M, K);
+    };
     auto conv1b = [&](const std::string& k, int M, int K) {  // Conv1d(k=1), always biased
       return pack_upload_1x1(pool_, host(k + ".weight").data(), host(k + ".bias").data(), M, K);
     };
@@ -148,7 +153,7 @@ class HintNet final : public Net {
           bl.n1.w = vec(n + ".norm1.body.weight");
           if (with_bias_ln_) bl.n1.b = vec(n + ".norm1.body.bias");
           const std::string a = n + ".attn";
-          bl.qkv = conv1(a + ".qkv", 3 * C, C);
+          bl.qkv = conv1_ln(a + ".qkv", n + ".norm1", 3 * C, C);
           bl.qkv_dw.w = vec(a + ".qkv_dwconv.weight");
           if (bias_) bl.qkv_dw.b = vec(a + ".qkv_dwconv.bias");
           bl.gate = conv1b(a + ".intra_modulator.gating_conv", C, C);
@@ -168,7 +173,7 @@ class HintNet final : public Net {
         }
         bl.n2.w = vec(n + ".norm2.body.weight");
         if (with_bias_ln_) bl.n2.b = vec(n + ".norm2.body.bias");
-        bl.pin = conv1(n + ".ffn.project_in", 2 * h, C);
+        bl.pin = conv1_ln(n + ".ffn.project_in", n + ".norm2", 2 * h, C);
         bl.ffn_dw.w = vec(n + ".ffn.dwconv.weight");
         if (bias_) bl.ffn_dw.b = vec(n + ".ffn.dwconv.bias");
         bl.pout = conv1(n + ".ffn.project_out", C, h);
@@ -434,7 +439,7 @@ class HintNet final : public Net {
     g.x = x; g.y = y; g.epi = epi; g.r = r;
     g.imgs_per_group = 1;
     if (loader == LD_LN) {
-      g.mu = mu_; g.rstd = rstd_; g.lnw = ln->w; g.lnb = ln->b;
+      g.mu = mu_; g.rstd = rstd_; g.lnw = nullptr; g.lnb = nullptr;   // folded into w (conv1_ln)
       g.ln_center = with_bias_ln_ ? 1 : 0;
     }
     launch_gemm(g, loader, s);

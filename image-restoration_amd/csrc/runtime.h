@@ -149,6 +149,12 @@ struct PackedW {
   int M = 0, K = 0, Mpad = 0, Cin = 0;
 };
 PackedW pack_upload_1x1(WeightPool& pool, const float* w, const float* bias, int M, int K);
+// A 1x1 convolution that follows a LayerNorm with weight lnw [K] and bias lnb [K] (or null):
+//   W (n * lnw + lnb) + bias  =  (W diag(lnw)) n + (W lnb + bias)        (n = the normalised input)
+// so the packed weights carry lnw and the packed bias W lnb (summed in double); the GEMM's LayerNorm
+// loader is then called with lnw = lnb = null and only normalises.
+PackedW pack_upload_ln_1x1(WeightPool& pool, const float* w, const float* bias, const float* lnw, const float* lnb,
+                           int M, int K);
 PackedW pack_upload_3x3(WeightPool& pool, const float* w, const float* bias, int M, int Cin);
 PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, int M, int Cin, int ks);
 

@@ -193,6 +193,20 @@ PackedW pack_upload_1x1(WeightPool& pool, const float* w, const float* bias, int
   }
   return out;
 }
+PackedW pack_upload_ln_1x1(WeightPool& pool, const float* w, const float* bias, const float* lnw, const float* lnb,
+                           int M, int K) {
+  std::vector<float> wf((size_t)M * K), bf(M);
+  for (int o = 0; o < M; ++o) {
+    double c = bias ? (double)bias[o] : 0.0;
+    for (int k = 0; k < K; ++k) {
+      const float wv = w[(size_t)o * K + k];
+      wf[(size_t)o * K + k] = wv * lnw[k];
+      if (lnb) c += (double)wv * (double)lnb[k];
+    }
+    bf[o] = (float)c;
+  }
+  return pack_upload_1x1(pool, wf.data(), (bias || lnb) ? bf.data() : nullptr, M, K);
+}
 PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, int M, int Cin, int ks) {
   std::vector<float> packed;
   PackedW out;

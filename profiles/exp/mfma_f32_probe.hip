@@ -102,6 +102,82 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ in, float
   if (tid == 0) stamps[blockIdx.x] = Stamp{c1 - c0, r1 - r0};
 }
 
+// The first n_mfma_wg x 256 workgroups (n_mfma_wg per CU) run an MFMA loop (operands in registers, or B
+// re-read from LDS), the last 256 a loop of INDEPENDENT plain vector instructions (8 chains of
+// v_fma_f32), and each kind reports its own cycles: what a vector instruction costs a wave whose SIMD
+// is shared with waves that always have an MFMA queued.
+__global__ __launch_bounds__(256) void mixed(const float* __restrict__ in, float* __restrict__ out, int iters,
+                                             Stamp* stamps, int n_mfma_wg, int b_from_lds) {
+  __shared__ float lds[64 * 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool mfma_wg = (int)blockIdx.x < 256 * n_mfma_wg;
+  for (int i = tid; i < 64 * 128; i += 256) lds[i] = in[(blockIdx.x * 97 + i) & 0xffff];
+  __syncthreads();
+  float a[8], bq[8];
+  for (int i = 0; i < 8; ++i) {
+    a[i] = in[(tid * 8 + i) & 0xffff];
+    bq[i] = in[(tid * 8 + i + 4099) & 0xffff];
+  }
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  if (mfma_wg) {
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    if (b_from_lds) {
+      const float* bp = lds + 4 * (lane & 31) + (lane >> 5) * 128;
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bp[(2 * i) * 128 + (it & 3) * 2048]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b4[j], acc[j], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[(i + j) & 7], acc[j], 0, 0, 0);
+      }
+    }
+    for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][7];
+  } else {
+    // iters / 4 trips x 64 v_fma: a quarter of an MFMA workgroup's instruction count
+    for (int it = 0; it < iters / 4; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = fmaf(a[i], bq[i], bq[(i + u) & 7]);
+    }
+    for (int i = 0; i < 8; ++i) s += a[i];
+  }
+  out[blockIdx.x * 256 + tid] = s;
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) stamps[blockIdx.x] = Stamp{c1 - c0, r1 - r0};
+}
+
+void run_mixed(const float* in, float* out, Stamp* st, int n_mfma_wg, int b_from_lds) {
+  const int iters = 4000, blocks = 256 * (n_mfma_wg + 1);
+  for (int rep = 0; rep < 10; ++rep)
+    hipLaunchKernelGGL(mixed, dim3(blocks), dim3(256), 0, 0, in, out, iters, st, n_mfma_wg, b_from_lds);
+  CK(hipDeviceSynchronize());
+  std::vector<Stamp> h(blocks);
+  CK(hipMemcpy(h.data(), st, blocks * sizeof(Stamp), hipMemcpyDeviceToHost));
+  std::vector<double> m, v;
+  for (int i = 0; i < 256 * n_mfma_wg; ++i) m.push_back((double)h[i].cyc);
+  for (int i = 256 * n_mfma_wg; i < blocks; ++i) v.push_back((double)h[i].cyc);
+  std::sort(m.begin(), m.end());
+  std::sort(v.begin(), v.end());
+  const double n_valu = iters / 4 * 64.0, n_mfma = iters * 32.0;
+  if (n_mfma_wg == 0)
+    printf("vector-only workgroup (1 per CU): %.1f cycles per v_fma_f32 per wave\n", v[128] / n_valu);
+  else
+    printf("%d MFMA workgroup(s) (B from %s) + 1 vector workgroup per CU: %.1f cycles per MFMA per wave, %.1f cycles per v_fma_f32 beside them\n",
+           n_mfma_wg, b_from_lds ? "LDS" : "registers", m[m.size() / 2] / n_mfma, v[128] / n_valu);
+}
+
 template <int MODE, int NACC>
 void run(const char* what, int wg_per_cu, const float* in, float* out, Stamp* st) {
   const int iters = 4000, blocks = 256 * wg_per_cu;
@@ -149,5 +225,10 @@ int main() {
   run<2, 4>("32x32x2, B from LDS as the compiler schedules it", 2, in, out, st);
   run<3, 4>("32x32x2, B from LDS one k-step ahead", 1, in, out, st);
   run<3, 4>("32x32x2, B from LDS one k-step ahead", 2, in, out, st);
+  run_mixed(in, out, st, 0, 0);
+  run_mixed(in, out, st, 1, 0);
+  run_mixed(in, out, st, 2, 0);
+  run_mixed(in, out, st, 1, 1);
+  run_mixed(in, out, st, 2, 1);
   return 0;
 }

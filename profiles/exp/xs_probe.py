@@ -41,11 +41,16 @@ hw = st[:, 0, 1]
 xcc, hwid = hw >> 32, hw & 0xffffffff
 cu = (xcc << 8) | (((hwid >> 13) & 7) << 5) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 15)
 print(f"{n_wg} workgroups on {len(np.unique(cu))} distinct (xcc, se, sh, cu)")
-n_items = int(((st[0, 0, 4:47:2] != 0)).sum())
+n_items = int(((st[0, 0, 4:40:2] != 0)).sum())
 us = lambda c: c / 2390.0
 print("median per-wave phase lengths (us at 2.39 GHz):")
 print(f"  tile load (entry -> barrier)      {us(np.median(st[:, :, 2] - t0)):8.2f}")
 print(f"  LayerNorm (stats + normalise)     {us(np.median(st[:, :, 3] - st[:, :, 2])):8.2f}")
+if st[0, 0, 40]:
+    seq = [(0, "entry"), (40, "tile loads issued"), (2, "tile arrived, local sums"), (42, "mean exchanged"),
+           (43, "variance exchanged"), (44, "normalised tile written"), (3, "barrier passed")]
+    for (a_, _), (b__, name) in zip(seq[:-1], seq[1:]):
+        print(f"    -> {name:28s} {us(np.median(st[:, :, b__] - st[:, :, a_])):8.2f}")
 prev = st[:, :, 3]
 for i in range(n_items):
     a, b_ = st[:, :, 4 + 2 * i], st[:, :, 5 + 2 * i]
@@ -65,3 +70,29 @@ for c in np.unique(cu)[:64]:
 print(f"  mean workgroups resident per CU while one runs: {np.mean(res):.2f}")
 span = [(st[cu == c, 0, 47].max() - st[cu == c, 0, 0].min()) for c in np.unique(cu)]
 print(f"  per-CU span first entry -> last exit: median {us(np.median(span)):.1f} us over {np.median([np.sum(cu == c) for c in np.unique(cu)]):.0f} workgroups")
+
+# per SIMD: fraction of the span during which at least one wave is inside an MFMA loop, and the mean number
+hw_w = st[:, :, 1]
+simd = (hw_w & 0xffffffff) >> 4 & 3
+cov, dens = [], []
+for c in np.unique(cu)[:48]:
+    for sd in range(4):
+        sel = (cu[:, None] == c) & (simd == sd)
+        if not sel.any():
+            continue
+        ev = []
+        for i in range(n_items):
+            start = st[:, :, 3] if i == 0 else st[:, :, 5 + 2 * (i - 1)]
+            ev += [(t, 1) for t in start[sel]] + [(t, -1) for t in st[:, :, 4 + 2 * i][sel]]
+        ev.sort()
+        t_lo, t_hi = st[:, :, 0][sel].min(), st[:, :, 47][sel].max()
+        depth, last, busy, area = 0, t_lo, 0, 0
+        for t, d in ev:
+            if depth > 0:
+                busy += t - last
+            area += depth * (t - last)
+            depth += d
+            last = t
+        cov.append(busy / (t_hi - t_lo))
+        dens.append(area / (t_hi - t_lo))
+print(f"  per SIMD: some wave inside an MFMA loop {100 * np.mean(cov):.1f} % of the time; mean waves inside a loop {np.mean(dens):.2f}")
