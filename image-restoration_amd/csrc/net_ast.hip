@@ -93,7 +93,9 @@ class AstNet final : public Net {
             const auto& bkv = host(a + ".qkv.to_kv.bias");
             b.insert(b.end(), bkv.begin(), bkv.end());
           }
-          bl.qkv = pack_upload_1x1(pool_, w.data(), qkv_bias_ ? b.data() : nullptr, 3 * C, C);
+          // norm1 (weight and bias) folded into the projection: the GEMM's loader only normalises
+          bl.qkv = pack_upload_ln_1x1(pool_, w.data(), qkv_bias_ ? b.data() : nullptr, host(n + ".norm1.weight").data(),
+                                      host(n + ".norm1.bias").data(), 3 * C, C);
           bl.proj = pack_upload_1x1(pool_, host(a + ".proj.weight").data(), host(a + ".proj.bias").data(), C, C);
           bl.table = vec(a + ".relative_position_bias_table");
           const auto& wv = host(a + ".w");
@@ -297,7 +299,7 @@ class AstNet final : public Net {
       GemmArgs g{};
       g.B = B; g.M = 3 * C; g.K = C; g.P = P; g.Mpad = bl.qkv.Mpad; g.wt = bl.qkv.wt; g.bias = bl.qkv.bias;
       g.x = x; g.y = t1; g.epi = EP_STORE; g.imgs_per_group = 1;
-      g.mu = mu_; g.rstd = rstd_; g.lnw = bl.n1w; g.lnb = bl.n1b; g.ln_center = 1;
+      g.mu = mu_; g.rstd = rstd_; g.lnw = nullptr; g.lnb = nullptr; g.ln_center = 1;
       launch_gemm(g, LD_LN, s);
       WinAttnArgs wa{};
       wa.B = B; wa.C = C; wa.H = H; wa.W = W; wa.heads = bl.heads; wa.shift = bl.shift;

@@ -66,6 +66,11 @@ class Astv2Net final : public Net {
     auto conv1 = [&](const std::string& k, int M, int K) {
       return pack_upload_1x1(pool_, host(k + ".weight").data(), bias_ ? host(k + ".bias").data() : nullptr, M, K);
     };
+    auto conv1_ln = [&](const std::string& k, const std::string& ln, int M, int K) {  // LayerNorm affine folded in
+      return pack_upload_ln_1x1(pool_, host(k + ".weight").data(), bias_ ? host(k + ".bias").data() : nullptr,
+                                host(ln + ".body.weight").data(),
+                                with_bias_ln_ ? host(ln + ".body.bias").data() : nullptr, M, K);
+    };
     auto conv3 = [&](const std::string& k, int M, int Cin, bool b) {
       return pack_upload_3x3(pool_, host(k + ".weight").data(), b ? host(k + ".bias").data() : nullptr, M, Cin);
     };
@@ -78,7 +83,7 @@ class Astv2Net final : public Net {
           bl.n1w = vec(n + ".norm1.body.weight");
           if (with_bias_ln_) bl.n1b = vec(n + ".norm1.body.bias");
           const std::string a = n + ".attn";
-          bl.qkv = conv1(a + ".qkv", 3 * C, C);
+          bl.qkv = conv1_ln(a + ".qkv", n + ".norm1", 3 * C, C);
           bl.qkv_dw_w = vec(a + ".qkv_dwconv.weight");
           if (bias_) bl.qkv_dw_b = vec(a + ".qkv_dwconv.bias");
           bl.proj = conv1(a + ".project_out", C, C);
@@ -257,7 +262,7 @@ class Astv2Net final : public Net {
     const TV t1 = tv(t1_, (long)t1_per_), t2 = tv(t2_, (long)t2_per_);
     if (bl.att) {
       if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
-      gemm(bl.qkv, x, t1, B, P, EP_STORE, TV{}, s, LD_LN, bl.n1w, bl.n1b);
+      gemm(bl.qkv, x, t1, B, P, EP_STORE, TV{}, s, LD_LN);   // norm1 folded into bl.qkv
       launch_dwconv3x3(t1, bl.qkv_dw_w, bl.qkv_dw_b, t2, B, 3 * C, H, W, 0, s);
       HeadAttnScratch sc;
       head_attn_scratch_carve(B, C, P, head_attn_splits(B, C, P), attn_scratch_, &sc);

@@ -88,6 +88,11 @@ class FproNet final : public Net {
     auto conv1 = [&](const std::string& k, int M, int K) {
       return pack_upload_1x1(pool_, host(k + ".weight").data(), bias_ ? host(k + ".bias").data() : nullptr, M, K);
     };
+    auto conv1_ln = [&](const std::string& k, const std::string& ln, int M, int K) {  // LayerNorm affine folded in
+      return pack_upload_ln_1x1(pool_, host(k + ".weight").data(), bias_ ? host(k + ".bias").data() : nullptr,
+                                host(ln + ".body.weight").data(),
+                                with_bias_ln_ ? host(ln + ".body.bias").data() : nullptr, M, K);
+    };
     auto conv3 = [&](const std::string& k, int M, int Cin, bool b) {
       return pack_upload_3x3(pool_, host(k + ".weight").data(), b ? host(k + ".bias").data() : nullptr, M, Cin);
     };
@@ -100,7 +105,7 @@ class FproNet final : public Net {
           bl.n1w = vec(n + ".norm1.body.weight");
           if (with_bias_ln_) bl.n1b = vec(n + ".norm1.body.bias");
           const std::string a = n + ".attn";
-          bl.qkv = conv1(a + ".qkv", 3 * C, C);
+          bl.qkv = conv1_ln(a + ".qkv", n + ".norm1", 3 * C, C);
           bl.qkv_dw_w = vec(a + ".qkv_dwconv.weight");
           if (bias_) bl.qkv_dw_b = vec(a + ".qkv_dwconv.bias");
           bl.proj = conv1(a + ".project_out", C, C);
@@ -108,7 +113,7 @@ class FproNet final : public Net {
         }
         bl.n2w = vec(n + ".norm2.body.weight");
         if (with_bias_ln_) bl.n2b = vec(n + ".norm2.body.bias");
-        bl.pin = conv1(n + ".ffn.project_in", 2 * h, C);
+        bl.pin = conv1_ln(n + ".ffn.project_in", n + ".norm2", 2 * h, C);
         bl.ffn_dw_w = vec(n + ".ffn.dwconv.weight");
         if (bias_) bl.ffn_dw_b = vec(n + ".ffn.dwconv.bias");
         bl.pout = conv1(n + ".ffn.project_out", C, h);
@@ -414,7 +419,7 @@ class FproNet final : public Net {
     if (bl.att) {
       // MDTA (fpro_arch.py:128-144): rows normalised as x / (||x|| + 1e-12) (:10-12)
       if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
-      gemm(bl.qkv, x, t1, B, P, EP_STORE, TV{}, s, LD_LN, bl.n1w, bl.n1b);
+      gemm(bl.qkv, x, t1, B, P, EP_STORE, TV{}, s, LD_LN);   // norm1 folded into bl.qkv
       launch_dwconv3x3(t1, bl.qkv_dw_w, bl.qkv_dw_b, t2, B, 3 * C, H, W, 0, s);
       HeadAttnScratch sc;
       head_attn_scratch_carve(B, C, P, head_attn_splits(B, C, P), attn_scratch_, &sc);
@@ -432,7 +437,7 @@ class FproNet final : public Net {
     }
     // GDFN (fpro_arch.py:109-114)
     if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
-    gemm(bl.pin, x, t1, B, P, EP_STORE, TV{}, s, LD_LN, bl.n2w, bl.n2b);
+    gemm(bl.pin, x, t1, B, P, EP_STORE, TV{}, s, LD_LN);   // norm2 folded into bl.pin
     launch_dwconv3x3(t1, bl.ffn_dw_w, bl.ffn_dw_b, t2, B, 2 * h, H, W, 1, s);
     gemm(bl.pout, t2, x, B, P, EP_RESID, x, s);
   }

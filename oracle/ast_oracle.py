@@ -13,7 +13,7 @@ from typing import Callable, Optional
 import torch
 import torch.nn.functional as F
 
-from .common import Params, as_params, gelu
+from .common import Params, as_params, gelu, leaky_relu, token_layernorm
 
 Tap = Optional[Callable[[str, torch.Tensor], None]]
 LAYERS = ["encoderlayer_0", "encoderlayer_1", "encoderlayer_2", "encoderlayer_3", "conv",
@@ -151,7 +151,7 @@ def transformer_block(p: Params, pre: str, x: torch.Tensor, heads: int, win: int
     H = W = int(math.sqrt(L))
     if att:
         mask = shift_attn_mask(H, W, win, shift) if shift > 0 else None
-        t = F.layer_norm(x, (C,), p[pre + ".norm1.weight"], p[pre + ".norm1.bias"], 1e-5).reshape(B, H, W, C)
+        t = token_layernorm(x, p[pre + ".norm1.weight"], p[pre + ".norm1.bias"]).reshape(B, H, W, C)
         if shift > 0:
             t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
         wins = window_partition(t, win).reshape(-1, win * win, C)
@@ -160,7 +160,7 @@ def transformer_block(p: Params, pre: str, x: torch.Tensor, heads: int, win: int
         if shift > 0:
             t = torch.roll(t, shifts=(shift, shift), dims=(1, 2))
         x = x + t.reshape(B, H * W, C)
-    x = x + frfn(p, pre + ".mlp", F.layer_norm(x, (C,), p[pre + ".norm2.weight"], p[pre + ".norm2.bias"], 1e-5))
+    x = x + frfn(p, pre + ".mlp", token_layernorm(x, p[pre + ".norm2.weight"], p[pre + ".norm2.bias"]))
     if tap:
         tap(pre + ".out", x.clone())
     return x
@@ -200,7 +200,7 @@ def ast_forward(state: dict, x: torch.Tensor, cfg: Optional[dict] = None, tap: T
         return _to_tokens(F.conv_transpose2d(_to_img(t), p[f"upsample_{i}.deconv.0.weight"],
                                              p[f"upsample_{i}.deconv.0.bias"], stride=2))
 
-    y = _to_tokens(F.leaky_relu(F.conv2d(x, p["input_proj.proj.0.weight"], p["input_proj.proj.0.bias"], padding=1), 0.01))
+    y = _to_tokens(leaky_relu(F.conv2d(x, p["input_proj.proj.0.weight"], p["input_proj.proj.0.bias"], padding=1)))
     c0 = layer(0, y)
     c1 = layer(1, down(0, c0))
     c2 = layer(2, down(1, c1))

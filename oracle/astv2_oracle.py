@@ -9,7 +9,7 @@ from typing import Callable, Optional
 
 import torch
 
-from .common import (Params, as_params, channel_layernorm, conv1x1, conv3x3, gelu, pixel_shuffle2,
+from .common import (ASSUMPTIONS, Params, as_params, channel_layernorm, conv1x1, conv3x3, gelu, pixel_shuffle2,
                      pixel_unshuffle2)
 
 FFN_GROUPS = 12   # FeedForward.groups, :82
@@ -37,7 +37,9 @@ def stage_plan(cfg: dict):
     ]
 
 
-def l2_normalize_rows(x: torch.Tensor, eps: float = 1e-30) -> torch.Tensor:
+def l2_normalize_rows(x: torch.Tensor, eps: float = None) -> torch.Tensor:
+    """jt.normalize(x, dim=-1) (:174-175): x / sqrt(max(sum x^2, eps)), eps = ASSUMPTIONS.normalize_eps."""
+    eps = ASSUMPTIONS.normalize_eps if eps is None else eps
     n2 = (x * x).sum(dim=-1, keepdim=True)
     return x / torch.sqrt(torch.clamp(n2, min=eps))
 

@@ -29,3 +29,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_report_header(config):
+    """The Jittor-semantic assumptions the oracle runs under (oracle/common.py JittorAssumptions plus the
+    per-network switches), printed once per session so that a report states what was assumed."""
+    from oracle.common import ASSUMPTIONS
+    from oracle.fpro_oracle import FproSwitches
+    from oracle.hint_oracle import HintSwitches
+    lines = ["oracle assumptions (Jittor semantics, unverifiable offline): " + ", ".join(ASSUMPTIONS.describe())]
+    for sw in (HintSwitches(), FproSwitches()):
+        lines.append(f"  {type(sw).__name__}: " + ", ".join(f"{k}={v!r}" for k, v in vars(sw).items()))
+    return lines

@@ -256,3 +256,37 @@ def test_fpro_low_prompt_mean_is_the_dc_term():
     want = re * wr / (H * W)
     got = y.mean(dim=(2, 3))
     assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("field,value,arch", [
+    ("gelu", "tanh", "ASTv2"), ("gelu", "tanh", "AST"), ("variance", "unbiased", "ASTv2"), ("variance", "unbiased", "AST"),
+    ("layernorm_eps", 1e-2, "HINT"), ("leaky_relu_slope", 0.2, "AST"), ("pixel_shuffle_order", "grouped", "ASTv2"),
+    ("normalize_eps", 1e3, "ASTv2"),
+])
+def test_named_jittor_assumptions_are_live_switches(field, value, arch):
+    """Every switchable entry of JittorAssumptions changes the oracle's output when flipped (so the name is
+    wired to the arithmetic it describes) and the default set reproduces the unflipped result exactly."""
+    import dataclasses
+    from oracle import ast_oracle, astv2_oracle, common
+    from oracle.weights import make_ast_state, make_astv2_state, synthetic_images
+    if arch == "AST":
+        cfg = dict(ast_oracle.default_config(), depths=[1] * 9)
+        sd, run, x = make_ast_state(cfg, seed=2, gain=0.5), ast_oracle.ast_forward, synthetic_images(1, 128, 128, seed=3)
+    elif arch == "ASTv2":
+        cfg = dict(astv2_oracle.default_config(), dim=24, num_blocks=[1, 1, 1], num_refinement_blocks=1)
+        sd, run, x = make_astv2_state(cfg, seed=2, gain=0.5), astv2_oracle.astv2_forward, synthetic_images(1, 16, 24, seed=3)
+    else:
+        cfg = dict(ho.default_config(), dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+        sd, x = make_hint_state(cfg, seed=2, gain=0.6), synthetic_images(1, 16, 24, seed=3)
+        run = lambda s, t, c: ho.hint_forward(s, t, c, None)[0]
+    base = run(sd, torch.from_numpy(x), cfg).numpy()
+    saved = dataclasses.replace(common.ASSUMPTIONS)
+    try:
+        setattr(common.ASSUMPTIONS, field, value)
+        flipped = run(sd, torch.from_numpy(x), cfg).numpy()
+    finally:
+        for f in dataclasses.fields(saved):
+            setattr(common.ASSUMPTIONS, f.name, getattr(saved, f.name))
+    again = run(sd, torch.from_numpy(x), cfg).numpy()
+    assert np.array_equal(base, again)
+    assert np.abs(flipped - base).max() > 1e-6, f"{field}={value!r} did not reach the {arch} oracle"
