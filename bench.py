@@ -62,20 +62,109 @@ def hint_flops_per_image(cfg, h, w):
     return total
 
 
+def kernel_source_digest():
+    """sha256 over the GEMM kernel sources: the PMC traffic record under profiles/ is only valid for the
+    code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("gemm.hip", "common.h"):
+        with open(os.path.join(ROOT, "image-restoration_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(label, batch):
     """HBM bytes per launch of the kernel `label`, from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).
-    None when no pass was recorded for this launch shape and batch."""
+    (profiles/*_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), with the
+    kernel symbol and grid it was measured on.  (None, None) when no pass was recorded for this launch
+    shape and batch, or when the kernel sources have changed since the pass (stale record)."""
     import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    for path in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         with open(path) as fh:
             rec = json.load(fh)
-        if rec.get("op", "").startswith(label + " ") and f"(B={batch})" in rec.get("op", ""):
-            ks = list(rec.get("kernels", {}).values())
-            if ks:
-                return ks[0].get("hbm_bytes_per_launch")
-    return None
+        if not (rec.get("op", "").startswith(label + " ") and f"(B={batch})" in rec.get("op", "")):
+            continue
+        if rec.get("kernel_source_sha256") != kernel_source_digest():
+            return None, {"stale_record": os.path.basename(path)}
+        for sym, k in rec.get("kernels", {}).items():
+            return k.get("hbm_bytes_per_launch"), {"record": os.path.basename(path), "kernel_symbol": sym,
+                                                   "grid_x": k.get("grid_x")}
+    return None, None
+
+
+def _dominant(detail):
+    """(name, record) of the launch shape with the largest share of device time, with its roofline fraction."""
+    name, a = max(detail.items(), key=lambda kv: kv[1]["ms"])
+    family = name.split(" ")[0]
+    per_launch_s = a["ms"] / 1e3 / a["launches"]
+    if family.startswith("gemm") or family == "hint_chan_stats" or family.startswith("win_attn"):
+        ach = a["flops"] / a["launches"] / per_launch_s / 1e12
+        return name, {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
+    ach = a["bytes"] / a["launches"] / per_launch_s / 1e9
+    return name, {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+
+
+def run_extra_config(nets, arch, B, Hh, Ww, steps, warmup=2, crop=0, overlap=0, seed=7):
+    """One more configuration of BASELINE.json on this GPU (N = 1 only): the same timing discipline as the
+    headline (warm-up, K steps between synchronisations, inputs resident in HBM), then one pass with HIP
+    events around every launch for the model FLOP rate and the dominant launch shape."""
+    from jirf_hip import harness
+    from jirf_hip.synthetic import default_config, make_state, synthetic_images
+    from basicsr.models.archs import define_network
+    if arch not in nets:
+        cfg = default_config(arch)
+        net = define_network(dict(cfg, type=arch))
+        net.load_state_dict(make_state(arch, cfg, seed=1))
+        net.cuda(torch.cuda.current_device()).eval()
+        net.batch_mode = "per_image"
+        nets[arch] = net
+    net = nets[arch]
+    x = torch.from_numpy(synthetic_images(B, Hh, Ww, seed=seed, sigma=50 if arch == "HINT" else 0)).cuda()
+    need = {"HINT": 8, "ASTv2": 8, "FPro": 32, "AST": 128}[arch]
+    script = Hh % need != 0 or Ww % need != 0 or (arch == "AST" and Hh != Ww) or crop > 0
+
+    def step():
+        if arch == "HINT":
+            net.qv_cache = None
+        if crop:
+            return harness.restore_image(net, x, factor=8, crop_size=crop, overlap_size=overlap)
+        if script:
+            return harness.restore_image(net, x, factor=need, square_multiple=128 if arch == "AST" else None)
+        return net(x)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    assert bool(torch.isfinite(y).all()), "non-finite output"
+    nat = net.native()
+    nat.enable_kernel_timing(True)
+    detail, flops = {}, 0.0
+    step()
+    torch.cuda.synchronize()
+    for k in nat.kernel_times():
+        a = detail.setdefault(k["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        for f in ("ms", "flops", "bytes", "launches"):
+            a[f] += k[f]
+        flops += k["flops"]
+    nat.enable_kernel_timing(False)
+    rec = {"arch": arch, "batch": B, "height": Hh, "width": Ww,
+           "path": (f"script loop body: reflect pad to x8, {crop}x{crop} tiles overlap {overlap}, mean blend, crop, clamp" if crop else
+                    ("script loop body: reflect pad" + (" to the enclosing square (side % 128 == 0)" if arch == "AST" else f" to x{need}")
+                     + ", forward, crop, clamp") if script else "forward"),
+           "steps": steps, "ms_per_step": round(ms, 3), "ms_per_image": round(ms / B, 3),
+           "mp_per_s": round(B * Hh * Ww / 1e6 / (ms / 1e3), 3),
+           "model_tflops_per_s": round(flops / (ms / 1e3) / 1e12, 2),
+           "frac_of_f32_mfma_peak": round(flops / (ms / 1e3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+    if detail:
+        rec["dominant_kernel"] = _dominant(detail)[1]
+    return rec
 
 
 def main():
@@ -95,6 +184,8 @@ def main():
                     help="hand host buffers to the library (PCIe copies inside the timed region); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the `configs` array (the other shapes of the BASELINE metric, N = 1 only)")
     ap.add_argument("--detail", default=None, help="write the per-shape kernel table to this file")
     args = ap.parse_args()
 
@@ -106,7 +197,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1
+    # under torch.distributed.run the process group (RCCL) is set up even for one rank, so that the
+    # launcher path can be exercised on a one-GPU box
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -215,18 +308,12 @@ def main():
                              f"{v['bytes'] / (v['ms'] / 1e3) / 1e9 if v['ms'] else 0:8.1f} GB/s  {k}\n")
         tot_ms = sum(a["ms"] for a in acc.values())
         # the dominant kernel = the single launch shape with the largest share of device time
-        name, a = max(detail.items(), key=lambda kv: kv[1]["ms"])
-        family = name.split(" ")[0]
+        name, roof = _dominant(detail)
+        a = detail[name]
         per_launch_s = a["ms"] / 1e3 / a["launches"]
-        if family.startswith("gemm") or family == "hint_chan_stats":
-            ach = a["flops"] / a["launches"] / per_launch_s / 1e12
-            roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
-        else:
-            ach = a["bytes"] / a["launches"] / per_launch_s / 1e9
-            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-        roof.update({"traffic": pmc_traffic(name, B), "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+        traffic, measured_on = pmc_traffic(name, B)
+        roof.update({"traffic": traffic, "traffic_measured_on": measured_on,
+                     "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
                      "algorithmic_flops_per_launch": a["flops"] / a["launches"],
                      "launches_per_step": a["launches"] // args.steps,
                      "avg_launch_us": round(per_launch_s * 1e6, 2),
@@ -238,11 +325,25 @@ def main():
                               "gbs": round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) if v["ms"] > 0 else 0}
                           for k, v in sorted(acc.items(), key=lambda kv: -kv[1]["ms"])}
 
+    # the other configurations BASELINE.json's metric names, each timed on this GPU (N = 1, default run only)
+    if rank == 0 and world == 1 and not args.no_extra_configs and not args.host_io and \
+            (args.arch, Hh, Ww, args.crop_size) == ("HINT", 256, 256, 0):
+        nets = {"HINT": net}
+        extra = [("HINT", 1, 256, 256, 20, 0, 0), ("HINT", 1, 720, 1280, 4, 0, 0),
+                 ("AST", 16, 256, 256, 6, 0, 0), ("AST", 1, 256, 256, 20, 0, 0), ("AST", 1, 321, 481, 10, 0, 0),
+                 ("ASTv2", 1, 321, 481, 10, 0, 0), ("FPro", 1, 460, 620, 6, 256, 158)]
+        out["configs"] = []
+        for a_, b_, h_, w_, k_, c_, o_ in extra:
+            out["configs"].append(run_extra_config(nets, a_, b_, h_, w_, k_, crop=c_, overlap=o_))
+            if a_ != "HINT" and a_ in nets and all(e[0] != a_ for e in extra[extra.index((a_, b_, h_, w_, k_, c_, o_)) + 1:]):
+                del nets[a_]            # free the arena before the next network plans its own
+        net.batch_mode = "per_image"
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: one 256x256 image through the oracle on the host cores of this box
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
         torch.set_num_threads(cores)
-        xh = x.cpu()
+        xh = torch.from_numpy(x_host)
         # the only place the benchmark touches oracle/: the CPU restatement, as the reported baseline
         if args.arch == "HINT":
             from oracle.hint_oracle import hint_forward as _f

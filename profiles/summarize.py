@@ -83,7 +83,12 @@ if os.path.exists(p_sq):
               "mfma_busy_fraction": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0 / c["SQ_BUSY_CYCLES"],
               "wave_time_split": {k: c.get(k, 0.0) / c["SQ_WAVE_CYCLES"] for k in
                                   ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c.get("SQ_WAVE_CYCLES")}}
-res = {"isolated_kernel_trace": iso, "sq_counters": sq, "op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
+import hashlib
+_h = hashlib.sha256()
+for _n in ("gemm.hip", "common.h"):
+    with open(os.path.join("image-restoration_amd", "csrc", _n), "rb") as _fh:
+        _h.update(_fh.read())
+res = {"kernel_source_sha256": _h.hexdigest(), "isolated_kernel_trace": iso, "sq_counters": sq, "op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
        "algorithmic_bytes_per_launch": 4.0 * 16 * 65536 * (96 + 510),
        "kernels": out}
 with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:

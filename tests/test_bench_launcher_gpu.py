@@ -1,0 +1,27 @@
+"""bench.py under the launcher the driver uses for N > 1 (`python -m torch.distributed.run`), with one rank:
+the RANK / LOCAL_RANK / WORLD_SIZE plumbing, the RCCL process group bound to the rank's device, the barrier
+and the MAX all-reduce of the elapsed time all execute on the GPU, and the JSON line keeps its contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_runs_under_torch_distributed_run_with_one_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-extra-configs"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["unit"] == "MP/s" and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["config"]["batch_per_gpu"] == 2
