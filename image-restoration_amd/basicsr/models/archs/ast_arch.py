@@ -1,8 +1,8 @@
 """AST network_g class backed by libjirf_hip.so.
 
 Same constructor keywords, state-dict keys/shapes and call contract as the reference class
-(basicsr/models/archs/ast_arch.py:940-1256 of the reference).  Built for the shipped
-configuration family: `token_mlp="frfn"`, 8x8 windows, head_dim 32.  Like the reference, the
+(basicsr/models/archs/ast_arch.py:940-1256 of the reference), every `token_mlp` the reference takes
+("frfn" as shipped, "leff" the constructor default, "ffn" / "mlp"); 8x8 windows, head_dim 32.  Like the reference, the
 input must be square with a side that is a multiple of 128 (every module derives
 H = W = int(sqrt(L)), and 8x8 windows must tile the 1/16-resolution bottleneck).
 """
@@ -29,8 +29,6 @@ class AST(JirfModule):
                    shift_flag=bool(shift_flag))
         if token_mlp not in ("frfn", "leff", "ffn", "mlp"):
             raise Exception("FFN error!")
-        if token_mlp != "frfn":
-            raise NotImplementedError(f"AST token_mlp='{token_mlp}' is not built; the shipped configuration uses 'frfn'")
         super().__init__(cfg)
         self._out_ch = in_chans
 

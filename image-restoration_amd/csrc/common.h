@@ -167,7 +167,7 @@ void launch_psnr_stats(const float* a, const float* b, int C, int H, int W, int 
 // the GEMM's K-major packing wt[(tap * Cin + c) * Mpad + o].  Returns false (nothing launched)
 // when the shape is not one it is built for.
 bool try_launch_conv3x3_fewout(const struct GemmArgs& a, hipStream_t s);
-// gate: 0 plain, 1 gelu(dw(x1)) * dw(x2), 2 dw(x1) * x2, 3 gelu(dw(x1)) * x2.  wmod/wconv: ASTv2 partial convolution
+// gate: 0 plain, 1 gelu(dw(x1)) * dw(x2), 2 dw(x1) * x2, 3 gelu(dw(x1)) * x2, 4 gelu(dw(x)).  wmod/wconv: ASTv2 partial convolution
 // (channel c uses weight c % wmod when c % wmod < wconv, and is copied through otherwise).
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
                       int gate, hipStream_t s, int wmod = 0, int wconv = 0);

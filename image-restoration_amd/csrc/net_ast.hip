@@ -1,6 +1,8 @@
 // AST forward graph (reference basicsr/models/archs/ast_arch.py:940-1256) assembled from the
-// libjirf_hip kernels, for the shipped configuration family: token_mlp = "frfn", sparse window
-// attention (ASSA) in the bottleneck and decoder, FRFN-only encoder blocks.  Host code only.
+// libjirf_hip kernels: sparse window attention (ASSA) in the bottleneck and decoder (the class hard-codes
+// which layers attend and that they use the sparse form, :1017-1197), token MLP by `token_mlp`:
+// "frfn" (the shipped configuration, :453-513), "leff" (the constructor default, :407-450) or
+// "ffn" / "mlp" (:378-404).  Host code only.
 //
 // The reference carries tokens as [B, H*W, C] and converts to NCHW around every convolution; here
 // every tensor stays planar [C][H*W] (the same memory as NCHW), so those transposes vanish:
@@ -55,8 +57,7 @@ class AstNet final : public Net {
     const std::string mlp = cfg.get_str("token_mlp", "leff");
     const std::string proj = cfg.get_str("token_projection", "linear");
     JIRF_REQUIRE(mlp == "frfn" || mlp == "leff" || mlp == "ffn" || mlp == "mlp", JIRF_EINVAL, "FFN error!");
-    JIRF_REQUIRE(mlp == "frfn", JIRF_EINVAL,
-                 "AST: token_mlp='%s' is not built; the shipped configuration uses token_mlp='frfn'", mlp.c_str());
+    mlp_kind_ = mlp == "frfn" ? MLP_FRFN : mlp == "leff" ? MLP_LEFF : MLP_PLAIN;
     JIRF_REQUIRE(proj == "linear", JIRF_EINVAL, "Unsupported token projection!");
     JIRF_REQUIRE(depths_.size() == 9 && heads_.size() == 9, JIRF_EINVAL, "AST: depths and num_heads need 9 entries");
     JIRF_REQUIRE(E_ > 0 && E_ % 4 == 0, JIRF_EINVAL, "AST: embed_dim=%d must be a positive multiple of 4", E_);
@@ -107,9 +108,16 @@ class AstNet final : public Net {
         bl.n2w = vec(n + ".norm2.weight");
         bl.n2b = vec(n + ".norm2.bias");
         const std::string m = n + ".mlp";
-        bl.lin1 = pack_upload_1x1(pool_, host(m + ".linear1.0.weight").data(), host(m + ".linear1.0.bias").data(), 2 * h, C);
+        if (mlp_kind_ == MLP_PLAIN) {
+          bl.lin1 = pack_upload_1x1(pool_, host(m + ".fc1.weight").data(), host(m + ".fc1.bias").data(), h, C);
+          bl.lin2 = pack_upload_1x1(pool_, host(m + ".fc2.weight").data(), host(m + ".fc2.bias").data(), C, h);
+          continue;
+        }
+        const int h1 = mlp_kind_ == MLP_FRFN ? 2 * h : h;   // FRFN's linear1 feeds a gate: two halves
+        bl.lin1 = pack_upload_1x1(pool_, host(m + ".linear1.0.weight").data(), host(m + ".linear1.0.bias").data(), h1, C);
         bl.lin2 = pack_upload_1x1(pool_, host(m + ".linear2.0.weight").data(), host(m + ".linear2.0.bias").data(), C, h);
-        bl.pconv = pack_upload_conv(pool_, host(m + ".partial_conv3.weight").data(), nullptr, C / 4, C / 4, 3);
+        if (mlp_kind_ == MLP_FRFN)
+          bl.pconv = pack_upload_conv(pool_, host(m + ".partial_conv3.weight").data(), nullptr, C / 4, C / 4, 3);
         bl.dw_w = vec(m + ".dwconv.0.weight");
         bl.dw_b = vec(m + ".dwconv.0.bias");
       }
@@ -243,13 +251,21 @@ class AstNet final : public Net {
     add_param(n + ".norm2.weight", {C});
     add_param(n + ".norm2.bias", {C});
     const std::string m = n + ".mlp";
-    add_param(m + ".linear1.0.weight", {2 * h, C});
-    add_param(m + ".linear1.0.bias", {2 * h});
+    if (mlp_kind_ == MLP_PLAIN) {             // Mlp (ast_arch.py:378-404)
+      add_param(m + ".fc1.weight", {h, C});
+      add_param(m + ".fc1.bias", {h});
+      add_param(m + ".fc2.weight", {C, h});
+      add_param(m + ".fc2.bias", {C});
+      return;
+    }
+    const int h1 = mlp_kind_ == MLP_FRFN ? 2 * h : h;
+    add_param(m + ".linear1.0.weight", {h1, C});
+    add_param(m + ".linear1.0.bias", {h1});
     add_param(m + ".dwconv.0.weight", {h, 1, 3, 3});
     add_param(m + ".dwconv.0.bias", {h});
     add_param(m + ".linear2.0.weight", {C, h});
     add_param(m + ".linear2.0.bias", {C});
-    add_param(m + ".partial_conv3.weight", {C / 4, C / 4, 3, 3});
+    if (mlp_kind_ == MLP_FRFN) add_param(m + ".partial_conv3.weight", {C / 4, C / 4, 3, 3});
   }
 
   void carve(Arena& a, int B, int H, int W) {
@@ -310,8 +326,21 @@ class AstNet final : public Net {
       launch_window_attention(wa, s);
       gemm(bl.proj, tv_chan(t2, 0, P), x, B, P, EP_RESID, x, s);
     }
-    // FRFN: norm2 -> dense 3x3 on the first C/4 channels -> linear1 + GELU -> gelu(dw3x3(x1)) * x2 -> linear2
     launch_layernorm(x, bl.n2w, bl.n2b, tv_chan(t2, 0, P), B, C, P, 1, s);
+    if (mlp_kind_ == MLP_PLAIN) {
+      // Mlp (ast_arch.py:396-402): fc1 + GELU -> fc2 (dropout is the identity in eval)
+      gemm(bl.lin1, tv_chan(t2, 0, P), t1, B, P, EP_GELU, TV{}, s);
+      gemm(bl.lin2, t1, x, B, P, EP_RESID, x, s);
+      return;
+    }
+    if (mlp_kind_ == MLP_LEFF) {
+      // LeFF (ast_arch.py:425-450): linear1 + GELU -> depthwise 3x3 + GELU -> linear2; eca is the identity
+      gemm(bl.lin1, tv_chan(t2, 0, P), t1, B, P, EP_GELU, TV{}, s);
+      launch_dwconv3x3(t1, bl.dw_w, bl.dw_b, t2, B, h, H, W, 4, s);
+      gemm(bl.lin2, t2, x, B, P, EP_RESID, x, s);
+      return;
+    }
+    // FRFN: norm2 -> dense 3x3 on the first C/4 channels -> linear1 + GELU -> gelu(dw3x3(x1)) * x2 -> linear2
     conv(bl.pconv, tv_chan(t2, 0, P), tv_chan(t2, C, P), B, H, W, 3, 1, 1, EP_STORE, TV{}, s);
     {
       GemmArgs g{};
@@ -361,6 +390,8 @@ class AstNet final : public Net {
     conv(out_proj_, cat[0], yout, B, H, W, 3, 1, 1, dd_in_ == 3 ? EP_RESID : EP_STORE, dd_in_ == 3 ? xin : TV{}, s);
   }
 
+  enum { MLP_FRFN = 0, MLP_LEFF = 1, MLP_PLAIN = 2 };
+  int mlp_kind_ = MLP_FRFN;
   int img_size_, in_chans_, dd_in_, E_, win_;
   std::vector<int> depths_, heads_;
   double mlp_ratio_, qk_scale_;

@@ -283,6 +283,7 @@ void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStrea
 //   MODE 1  y[c] = gelu(dw(x[c])) * dw(x[c + Ch])   for c < Ch = C/2   (HINT GDFN)
 //   MODE 2  y[c] = dw(x[c]) * x[c + Ch]              (ASTv2 FeedForward: second half un-convolved)
 //   MODE 3  y[c] = gelu(dw(x[c])) * x[c + Ch]        (AST FRFN gate)
+//   MODE 4  y[c] = gelu(dw(x[c]))                    (AST LeFF: depthwise conv + GELU, no gate)
 // wmod > 0 (MODE 0 only) selects the "partial convolution" of ASTv2: channel c uses weight
 // c % wmod when c % wmod < wconv and is copied through otherwise.
 constexpr int DW_TH = 16, DW_TW = 64;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
                                                         int H, int W, int tiles_x, int tiles_y,
                                                         int wmod, int wconv) {
   constexpr int LW = DW_TW + 2 + 2;  // halo + pad so rows are 68 floats (odd multiple of 4 banks)
-  constexpr int NP = MODE == 0 ? 1 : 2;
+  constexpr int NP = (MODE == 0 || MODE == 4) ? 1 : 2;
   __shared__ float tile[NP][(DW_TH + 2) * LW];
   const int tid = threadIdx.x;
   int t = blockIdx.x;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   const int b = blockIdx.y;
   const int x0 = tx * DW_TW, y0 = ty * DW_TH;
   const long P = (long)H * W;
-  const int Cout = MODE == 0 ? C : C / 2;
+  const int Cout = (MODE == 0 || MODE == 4) ? C : C / 2;
 
 #pragma unroll
   for (int g = 0; g < NP; ++g) {
@@ -368,6 +369,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
       out[j] = res[0][j] * res[NP - 1][j];
     else if constexpr (MODE == 3)
       out[j] = gelu_erf_pw(res[0][j]) * res[NP - 1][j];
+    else if constexpr (MODE == 4)
+      out[j] = gelu_erf_pw(res[0][j]);
     else
       out[j] = res[0][j];
   }
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
                                                              int H, int W, int lx_log2, int R,
                                                              int tiles_x, int strips, int n_tasks,
                                                              int wmod, int wconv) {
-  constexpr int NP = MODE == 0 ? 1 : 2;
+  constexpr int NP = (MODE == 0 || MODE == 4) ? 1 : 2;
   const int lane = threadIdx.x & 63;
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (task >= n_tasks) return;  // whole wave
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
   const int px = (tx * LX + xq) * PX;
   const int ys = (ts * RW + yr) * R;
   const long P = (long)H * W;
-  const int Cout = MODE == 0 ? C : C / 2;
+  const int Cout = (MODE == 0 || MODE == 4) ? C : C / 2;
   const bool x_ok = px < W;
 
   struct Row { float v[PX + 2]; };
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
     for (int j = 0; j < PX; ++j) {
       if constexpr (MODE == 1 || MODE == 3) o[j] = gelu_erf_pw(res[0][j]) * res[NP - 1][j];
       else if constexpr (MODE == 2) o[j] = res[0][j] * res[1][j];
+      else if constexpr (MODE == 4) o[j] = gelu_erf_pw(res[0][j]);
       else o[j] = res[0][j];
     }
     if (x_ok && oy < H) {
@@ -606,17 +610,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const float* __rest
 
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
                       int gate, hipStream_t s, int wmod, int wconv) {
-  JIRF_REQUIRE(gate >= 0 && gate <= 3, JIRF_EINVAL, "dwconv3x3: mode %d", gate);
-  JIRF_REQUIRE(!gate || C % 2 == 0, JIRF_EINVAL, "dwconv3x3: gated forms need an even channel count");
+  JIRF_REQUIRE(gate >= 0 && gate <= 4, JIRF_EINVAL, "dwconv3x3: mode %d", gate);
+  JIRF_REQUIRE(gate == 0 || gate == 4 || C % 2 == 0, JIRF_EINVAL, "dwconv3x3: gated forms need an even channel count");
   JIRF_REQUIRE(wmod == 0 || (gate == 0 && wconv > 0 && wconv <= wmod && C % wmod == 0), JIRF_EINVAL,
                "dwconv3x3: bad partial-convolution pattern %d/%d for C=%d", wconv, wmod, C);
   const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
-  const int Cout = gate ? C / 2 : C;
+  const int Cout = (gate && gate != 4) ? C / 2 : C;
   const dim3 grid((unsigned)(tiles_x * tiles_y * Cout), B), block(256);
   const double px = (double)B * H * W;
   const char* nm = wmod ? "dwconv3x3_partial" : gate == 1 ? "dwconv3x3_gate" : gate == 2 ? "dwconv3x3_mul"
-                   : gate == 3 ? "dwconv3x3_gelu_mul" : "dwconv3x3";
-  Scope sc(intern_label("%s C%d H%d W%d", nm, C, H, W), 18.0 * px * (gate >= 2 ? C / 2 : C), 4.0 * px * (C + Cout), s);
+                   : gate == 3 ? "dwconv3x3_gelu_mul" : gate == 4 ? "dwconv3x3_gelu" : "dwconv3x3";
+  Scope sc(intern_label("%s C%d H%d W%d", nm, C, H, W), 18.0 * px * ((gate == 2 || gate == 3) ? C / 2 : C), 4.0 * px * (C + Cout), s);
   const uintptr_t addr = reinterpret_cast<uintptr_t>(x.p) | reinterpret_cast<uintptr_t>(y.p);
   const int PX = (W % 4 == 0 && x.bs % 4 == 0 && y.bs % 4 == 0 && (addr & 15) == 0)   ? 4
                  : (W % 2 == 0 && x.bs % 2 == 0 && y.bs % 2 == 0 && (addr & 7) == 0) ? 2
@@ -644,6 +648,7 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
     if (gate == 1) JIRF_DW_ROWS(1, 0, 0);
     else if (gate == 2) JIRF_DW_ROWS(2, 0, 0);
     else if (gate == 3) JIRF_DW_ROWS(3, 0, 0);
+    else if (gate == 4) JIRF_DW_ROWS(4, 0, 0);
     else JIRF_DW_ROWS(0, wmod, wconv);
 #undef JIRF_DW_ROWS
     JIRF_HIP_CHECK(hipGetLastError());
@@ -657,6 +662,9 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
                        tiles_x, tiles_y, 0, 0);
   else if (gate == 3)
     hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
+                       tiles_x, tiles_y, 0, 0);
+  else if (gate == 4)
+    hipLaunchKernelGGL(dwconv3x3_kernel<4>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,
                        tiles_x, tiles_y, 0, 0);
   else
     hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, block, 0, s, x.p, x.bs, w, bias, y.p, y.bs, C, H, W,

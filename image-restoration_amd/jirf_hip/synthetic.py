@@ -288,7 +288,8 @@ def make_astv2_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0) 
 
 def make_ast_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
     """AST state dict (ast_arch.py:95-117,219-273,453-474,561-596,600-674,940-1198 constructors),
-    token_mlp="frfn".  Includes the int32 `relative_position_index` buffers like a saved checkpoint."""
+    token MLP keys by cfg["token_mlp"] (frfn / leff / ffn).  Includes the int32 `relative_position_index`
+    buffers like a saved checkpoint."""
     block_window, default_config, layer_plan = ast_block_window, ast_default_config, ast_layer_plan
     cfg = cfg or default_config()
     g = _Gen(seed, gain)
@@ -325,11 +326,17 @@ def make_ast_state(cfg: dict | None = None, seed: int = 1, gain: float = 1.0) ->
             g.vec(pre + ".norm2.weight", c, 1.0, 0.1)
             g.vec(pre + ".norm2.bias", c, 0.0, 0.1)
             m = pre + ".mlp"
-            linear(m + ".linear1.0", 2 * h, c)
+            kind = cfg.get("token_mlp", "leff")
+            if kind in ("ffn", "mlp"):
+                linear(m + ".fc1", h, c)
+                linear(m + ".fc2", c, h)
+                continue
+            linear(m + ".linear1.0", 2 * h if kind == "frfn" else h, c)
             g.kernel(m + ".dwconv.0.weight", (h, 1, 3, 3))
             g.vec(m + ".dwconv.0.bias", h, 0.0, 0.05)
             linear(m + ".linear2.0", c, h)
-            g.kernel(m + ".partial_conv3.weight", (c // 4, c // 4, 3, 3))
+            if kind == "frfn":
+                g.kernel(m + ".partial_conv3.weight", (c // 4, c // 4, 3, 3))
     for i, (ci, co) in enumerate(((E, 2 * E), (2 * E, 4 * E), (4 * E, 8 * E), (8 * E, 16 * E))):
         g.kernel(f"dowsample_{i}.conv.0.weight", (co, ci, 4, 4))
         g.vec(f"dowsample_{i}.conv.0.bias", co, 0.0, 0.05)

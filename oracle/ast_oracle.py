@@ -1,7 +1,7 @@
 """Oracle for the AST forward (test infrastructure, parity unpinned).
 
-Restates ``basicsr/models/archs/ast_arch.py`` of the reference in torch-CPU fp32 for the shipped
-configuration family (``token_mlp="frfn"``, sparse window attention wherever attention is on);
+Restates ``basicsr/models/archs/ast_arch.py`` of the reference in torch-CPU fp32: sparse window attention
+wherever attention is on (the class hard-codes that), token MLP by ``token_mlp`` (frfn as shipped, leff, ffn / mlp);
 line numbers in the docstrings refer to that file.  Tokens are kept as ``[B, L, C]`` like the
 reference, with ``H = W = int(sqrt(L))``.
 """
@@ -144,8 +144,38 @@ def frfn(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
     return F.linear(x1 * x2, p[pre + ".linear2.0.weight"], p[pre + ".linear2.0.bias"])
 
 
+def leff(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """LeFF.execute (:425-450): linear1 + GELU -> NCHW -> depthwise 3x3 (bias) + GELU -> tokens -> linear2;
+    `eca` is nn.Identity (:421)."""
+    b, hw, c = x.shape
+    hh = int(math.sqrt(hw))
+    t = gelu(F.linear(x, p[pre + ".linear1.0.weight"], p[pre + ".linear1.0.bias"]))
+    h = t.shape[-1]
+    t = t.reshape(b, hh, hh, h).permute(0, 3, 1, 2)
+    t = gelu(F.conv2d(t, p[pre + ".dwconv.0.weight"], p[pre + ".dwconv.0.bias"], padding=1, groups=h))
+    t = t.permute(0, 2, 3, 1).reshape(b, hw, h)
+    return F.linear(t, p[pre + ".linear2.0.weight"], p[pre + ".linear2.0.bias"])
+
+
+def mlp(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """Mlp.execute (:396-402): fc1 -> GELU -> fc2 (dropout is the identity in eval)."""
+    return F.linear(gelu(F.linear(x, p[pre + ".fc1.weight"], p[pre + ".fc1.bias"])), p[pre + ".fc2.weight"],
+                    p[pre + ".fc2.bias"])
+
+
+def token_mlp(kind: str):
+    """TransformerBlock.__init__ (:741-757): 'ffn' / 'mlp' -> Mlp, 'leff' -> LeFF, 'frfn' -> FRFN."""
+    if kind in ("ffn", "mlp"):
+        return mlp
+    if kind == "leff":
+        return leff
+    if kind == "frfn":
+        return frfn
+    raise Exception("FFN error!")
+
+
 def transformer_block(p: Params, pre: str, x: torch.Tensor, heads: int, win: int, shift: int,
-                      att: bool, tap: Tap = None) -> torch.Tensor:
+                      att: bool, tap: Tap = None, ffn=frfn) -> torch.Tensor:
     """TransformerBlock.execute (:768-842), `mask` argument None (as in every script)."""
     B, L, C = x.shape
     H = W = int(math.sqrt(L))
@@ -160,7 +190,7 @@ def transformer_block(p: Params, pre: str, x: torch.Tensor, heads: int, win: int
         if shift > 0:
             t = torch.roll(t, shifts=(shift, shift), dims=(1, 2))
         x = x + t.reshape(B, H * W, C)
-    x = x + frfn(p, pre + ".mlp", token_layernorm(x, p[pre + ".norm2.weight"], p[pre + ".norm2.bias"]))
+    x = x + ffn(p, pre + ".mlp", token_layernorm(x, p[pre + ".norm2.weight"], p[pre + ".norm2.bias"]))
     if tap:
         tap(pre + ".out", x.clone())
     return x
@@ -179,17 +209,16 @@ def _to_tokens(t: torch.Tensor) -> torch.Tensor:
 def ast_forward(state: dict, x: torch.Tensor, cfg: Optional[dict] = None, tap: Tap = None) -> torch.Tensor:
     """AST.execute (:1220-1256)."""
     cfg = cfg or default_config()
-    if cfg.get("token_mlp", "leff") != "frfn":
-        raise NotImplementedError("only token_mlp='frfn' (the shipped configuration) is restated")
     p = as_params(state)
     x = x.float()
     plan = layer_plan(cfg)
+    ffn = token_mlp(cfg.get("token_mlp", "leff"))
 
     def layer(i, t):
         name, _, div, depth, heads, att = plan[i]
         for j in range(depth):
             win, shift = block_window(cfg, div, j)
-            t = transformer_block(p, f"{name}.blocks.{j}", t, heads, win, shift, att, tap)
+            t = transformer_block(p, f"{name}.blocks.{j}", t, heads, win, shift, att, tap, ffn)
         return t
 
     def down(i, t):

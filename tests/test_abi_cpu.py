@@ -153,7 +153,13 @@ def test_ast_constructor_contract():
     from basicsr.models.archs import define_network
     net = define_network(dict(type="AST", token_mlp="frfn", some_unknown_option=1))   # **kwargs is swallowed
     assert type(net).__name__ == "AST"
-    with pytest.raises(NotImplementedError):
-        define_network(dict(type="AST"))                                              # default token_mlp="leff"
+    leff = define_network(dict(type="AST"))                                           # default token_mlp="leff"
+    specs = dict(leff._specs)
+    assert not any("partial_conv3" in k for k in specs)
+    assert tuple(specs["encoderlayer_0.blocks.0.mlp.linear1.0.weight"]) == (128, 32)
+    plain = define_network(dict(type="AST", token_mlp="ffn"))
+    assert "conv.blocks.1.mlp.fc2.bias" in dict(plain._specs)
+    with pytest.raises(Exception, match="FFN error"):
+        define_network(dict(type="AST", token_mlp="nope"))
     with pytest.raises(TypeError):
         define_network(dict(type="ASTv2", some_unknown_option=1))                     # no **kwargs there

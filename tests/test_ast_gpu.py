@@ -39,6 +39,23 @@ def test_network_b1(name, cfg_update, S):
     assert abs(psnr(y, x) - psnr(y_ref, x)) < 0.01
 
 
+@pytest.mark.parametrize("token_mlp", ["leff", "ffn", "mlp"])
+def test_other_token_mlps(token_mlp):
+    """The token MLPs the shipped YAML does not select (ast_arch.py:741-757): 'leff' is what the bare
+    constructor AST() builds (LeFF, :407-450), 'ffn' / 'mlp' the plain Mlp (:378-404)."""
+    from basicsr.models.archs import define_network
+    cfg = dict(so.default_config(), token_mlp=token_mlp)
+    sd = make_ast_state(cfg, seed=7, gain=0.5)
+    x = synthetic_images(1, 128, 128, seed=44)
+    y_ref = so.ast_forward(sd, torch.from_numpy(x), cfg).numpy()
+    net = define_network(dict(type="AST")) if token_mlp == "leff" else define_network(dict(cfg, type="AST"))
+    net.load_state_dict(sd)
+    y = net.cuda().eval()(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = max_abs(y, y_ref)
+    print(f"[token_mlp={token_mlp}] max|dy| = {err:.2e}")
+    assert err < TOL
+
+
 @pytest.mark.parametrize("batch_mode", ["coupled", "per_image"])
 def test_batch_semantics(batch_mode):
     """bmm_4d pairs q with k of another (window, head) over the whole call: a literal B=2 call mixes
@@ -64,7 +81,5 @@ def test_rejects_what_the_reference_cannot_run():
         with pytest.raises(ValueError):
             net(torch.zeros(*shape).cuda())
     from basicsr.models.archs import define_network
-    with pytest.raises(NotImplementedError):
-        define_network(dict(type="AST"))            # ctor default token_mlp="leff" is not built
     with pytest.raises(Exception, match="FFN error"):
         define_network(dict(type="AST", token_mlp="nope"))
