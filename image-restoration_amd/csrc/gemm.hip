@@ -1072,6 +1072,166 @@ extern "C" int jirf_debug_xs_probe(unsigned long long* host_out) {
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary form for short outputs (M <= 96: the project_out / gate / attention-tail GEMMs,
+// whose activations are several times wider than their outputs, so they run at the HBM bound).
+// The whole packed weight matrix sits in LDS ([Kp][MT * 32], loaded once per workgroup); every wave
+// is its own pipeline with no barrier after that: it walks over groups of 64 pixels, streaming the
+// activation rows straight from global memory into MFMA B fragments (a lane holds two adjacent
+// pixels of rows k, k + 1: 256 contiguous bytes per row and load) through a window of WS_WIN k-steps
+// that runs on into the wave's next pixel group, so ~WS_WIN loads per wave stay in flight against the
+// HBM latency; A fragments come from LDS (one ds_read per 32-row tile and k-step, feeding 2 MFMAs).
+// The activation tensor is read exactly once and nothing but the weights passes through LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int WS_WIN = 16;     // k-steps of activation fragments in flight per wave
+constexpr int WS_WAVES = 8;
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(64 * WS_WAVES, 1) void gemm_ws_kernel(const GemmArgs a, const int groups_per_img,
+                                                                   const int total_groups) {
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  typedef float BV __attribute__((ext_vector_type(2)));
+  typedef unsigned UV __attribute__((ext_vector_type(2)));
+  constexpr int MW = MT * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int K = a.K, P = a.P, M = a.M;
+  const int Kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  const int nsteps = Kp >> 1;
+  float* __restrict__ Ws = ws_smem;            // [Kp][MW]
+  float* __restrict__ st_bias = Ws + Kp * MW;  // [MW]
+  // ---- weights (and bias) into LDS: rows of the K-major packed matrix, first MW columns ---------------
+  for (int i = tid; i < Kp * (MW / 4); i += 64 * WS_WAVES) {
+    const int k = i / (MW / 4), c4 = (i - k * (MW / 4)) * 4;
+    *reinterpret_cast<float4*>(&Ws[k * MW + c4]) = *reinterpret_cast<const float4*>(a.wt + (long)k * a.Mpad + c4);
+  }
+  for (int m = tid; m < MW; m += 64 * WS_WAVES) st_bias[m] = (a.bias && m < M) ? a.bias[m] : 0.f;
+  __syncthreads();
+
+  // a wave's pixel groups: g = first, first + stride, ...  (64 pixels each, never across images)
+  const int stride = (int)gridDim.x * WS_WAVES;
+  int g = (int)blockIdx.x * WS_WAVES + wave;
+  if (g >= total_groups) return;
+  const int row2 = 2 * P * 4;                   // bytes per k-step (two activation rows)
+  // one descriptor per image: rows past K read as zero (range check), pixels past P belong to discarded columns
+  auto rsrc_of = [&](int grp) {
+    const int b = grp / groups_per_img;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x.p + (long)b * a.x.bs), 0, K * P * 4, 0x00020000);
+  };
+  auto voff_of = [&](int grp) {
+    const int b = grp / groups_per_img;
+    return (half * P + (grp - b * groups_per_img) * 64 + 2 * l31) * 4;
+  };
+  auto load_b = [&](__amdgpu_buffer_rsrc_t rs, int voff, int s) {
+    return __builtin_bit_cast(BV, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, s * row2, 0));
+  };
+  BV bw[WS_WIN];
+  {
+    const __amdgpu_buffer_rsrc_t r0 = rsrc_of(g);
+    const int v0 = voff_of(g);
+#pragma unroll
+    for (int i = 0; i < WS_WIN; ++i) bw[i] = load_b(r0, v0, i);   // nsteps >= WS_WIN is checked at launch
+  }
+  const float* __restrict__ ap = Ws + half * MW + l31;
+  while (g < total_groups) {
+    const int gn = g + stride < total_groups ? g + stride : g;
+    const __amdgpu_buffer_rsrc_t rs_c = rsrc_of(g), rs_n = rsrc_of(gn);
+    const int vo_c = voff_of(g), vo_n = voff_of(gn);
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
+    float af[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = ap[mt * 32];
+    // Batches of WS_WIN k-steps: the activation fragments of the NEXT batch (of the wave's next pixel group
+    // after the last batch) are requested up front, all WS_WIN of them, and are due only after this batch's
+    // 2 MT WS_WIN MFMAs (~2.5 us of matrix-pipe time at MT = 3): the HBM latency hides behind them.
+    for (int s0 = 0; s0 < nsteps; s0 += WS_WIN) {
+      const bool last = s0 + WS_WIN >= nsteps;
+      const __amdgpu_buffer_rsrc_t rs = last ? rs_n : rs_c;
+      const int vo = last ? vo_n : vo_c;
+      const int sb = last ? 0 : s0 + WS_WIN;
+      BV bn[WS_WIN];
+#pragma unroll
+      for (int i = 0; i < WS_WIN; ++i) bn[i] = load_b(rs, vo, sb + i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < WS_WIN; ++i) {
+        // the A fragments of the next k-step are requested before this k-step's MFMAs (the group's last
+        // k-step re-reads row 0: the same for every pixel group)
+        float an[MT];
+        const int sn = s0 + i + 1 < nsteps ? s0 + i + 1 : 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) an[mt] = ap[(2 * sn) * MW + mt * 32];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt], bw[i][j], acc[mt][j], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = an[mt];
+      }
+#pragma unroll
+      for (int i = 0; i < WS_WIN; ++i) bw[i] = bn[i];
+    }
+    // ---- epilogue -----------------------------------------------------------------------------------
+    const int b = g / groups_per_img;
+    const int col0 = (g - b * groups_per_img) * 64 + 2 * l31;
+    const bool full = MT * 32 <= M && (g - b * groups_per_img) * 64 + 64 <= P;   // every tile of the group alike
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m0 = mt * 32;
+      if (m0 >= M) continue;
+      float bias_r[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias_r[r] = st_bias[m0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+      if (full) store_rows_v<EPI, 2, true>(a, b, acc[mt], m0, half, col0, bias_r);
+      else store_rows_v<EPI, 2, false>(a, b, acc[mt], m0, half, col0, bias_r);
+    }
+    g += stride;
+  }
+}
+
+static bool try_launch_ws(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
+  static const bool off = std::getenv("JIRF_GEMM_NO_WS") != nullptr || std::getenv("JIRF_GEMM_TILE") != nullptr;
+  if (off || loader != LD_PLAIN || !vec || a.M > 96 || a.wt_bs != 0 || a.bias_bs != 0) return false;
+  if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_GELU_MUL) return false;
+  const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  const int MT = (a.M + 31) / 32;
+  const size_t smem = ((size_t)Kp * MT * 32 + MT * 32) * sizeof(float);
+  if (smem > 150 * 1024 || Kp / 2 < WS_WIN || a.k_split > 0 || (double)Kp * a.P * 4.0 >= 2147483648.0) return false;
+  auto al8 = [](const TV& t) { return t.bs % 2 == 0 && (reinterpret_cast<uintptr_t>(t.p) & 7) == 0; };
+  if (!al8(a.y) || ((a.epi == EP_RESID || a.epi == EP_GELU_MUL) && !al8(a.r))) return false;
+  const int groups_per_img = (a.P + 63) / 64;
+  const long total = (long)groups_per_img * a.B;
+  // enough pixel groups that every wave gets a few: the prefetch window then pays for itself
+  if (total < 256L * WS_WAVES * 2) return false;
+  const int grid = 256;
+#define JIRF_WS_CASE(N, E)                                                                               \
+  do {                                                                                                   \
+    static DynLdsOnce once;                                                                              \
+    allow_dynamic_lds(once, reinterpret_cast<const void*>(gemm_ws_kernel<N, E>), 152 * 1024);            \
+    hipLaunchKernelGGL((gemm_ws_kernel<N, E>), dim3(grid), dim3(64 * WS_WAVES), smem, s, a, groups_per_img, (int)total); \
+  } while (0)
+#define JIRF_WS_EPI(N)                                                                                   \
+  do {                                                                                                   \
+    if (a.epi == EP_RESID) JIRF_WS_CASE(N, EP_RESID);                                                    \
+    else if (a.epi == EP_GELU_MUL) JIRF_WS_CASE(N, EP_GELU_MUL);                                         \
+    else JIRF_WS_CASE(N, EP_STORE);                                                                      \
+  } while (0)
+  if (MT == 1) JIRF_WS_EPI(1);
+  else if (MT == 2) JIRF_WS_EPI(2);
+  else JIRF_WS_EPI(3);
+#undef JIRF_WS_EPI
+#undef JIRF_WS_CASE
+  JIRF_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 bool gemm_split_bf16_enabled() {
   static const bool on = std::getenv("JIRF_GEMM_SPLIT_BF16") && std::atoi(std::getenv("JIRF_GEMM_SPLIT_BF16")) != 0;
   return on;
@@ -1279,6 +1439,7 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   const bool xs = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
                   (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
   if ((xs || (gemm_split_bf16_enabled() && a.K <= 128 && loader == LD_PLAIN)) && try_launch_xs3(a, loader, vec, s)) return;
+  if (!xs && try_launch_ws(a, loader, vec, s)) return;
   if (xs) {
     // 128-pixel tiles need K <= 128 (LDS) and enough of them: an underfilled grid does better with 64-pixel
     // tiles (half the tile load per workgroup) than with more row splits of the wide ones

@@ -28,6 +28,9 @@ def gemm_tol(k, mag=1.0):
     (1, 1021, 384, 256),        # latent project_out (odd K)
     (1, 16, 3, 4096),           # tiny Cout
     (2, 192, 510, 128 * 128),   # big enough for the 128x128 tile
+    (2, 255, 96, 512 * 256 + 24),   # weight-stationary streaming kernel: 3 row tiles, odd K, a ragged last pixel group
+    (4, 127, 48, 256 * 256),        # ... 2 row tiles (the second half empty), odd K
+    (5, 96, 24, 240 * 256),         # ... 1 row tile, groups of one wave running into the next image
 ])
 def test_conv1x1(B, Cin, Cout, P):
     x, w, b = rnd(B, Cin, P), rnd(Cout, Cin, scale=Cin ** -0.5), rnd(Cout)
