@@ -108,7 +108,13 @@ struct GemmArgs {
   TV q, k;               // EP_AV_INTRA sources (unsorted q, k planes)
   const float* rq;       // EP_AV_INTRA: [B][C] reciprocal norms of q
   const float* rk;       // EP_AV_INTRA: [B][C]
+  // split-K workspace (optional): when the grid of the K-loop kernel would leave most CUs idle, the
+  // reduction is cut into slabs that are written here ([split][B][M][P]) and summed, in slab order, by a
+  // second kernel that also applies the epilogue.  Null: never split.
+  float* splitk_ws = nullptr;
+  size_t splitk_floats = 0;
 };
+constexpr size_t SPLITK_WS_FLOATS = (size_t)4 << 20;   // what the networks reserve in their arena (16 MiB)
 
 void launch_gemm(const GemmArgs& a, int loader, hipStream_t s);
 // true when the LD_LN loader computes the LayerNorm statistics itself (mu / rstd may be null)

@@ -232,9 +232,10 @@ __device__ __forceinline__ void load_bias16(const GemmArgs& a_in, int b, int rba
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int LOADER, bool VEC>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const GemmArgs a,
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const GemmArgs a_in,
                                                                         const int tiles_m,
-                                                                        const int tiles_n) {
+                                                                        const int tiles_n,
+                                                                        const int kt_per_split) {
   constexpr int BK = GEMM_BK;
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int WM = TM * 32, WN = TN * 32;
@@ -253,6 +254,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, half = lane >> 5;
 
+  // split-K (gridDim.y > 1): this workgroup reduces the chunks [kt0, kt1) and leaves its raw sums in slab
+  // blockIdx.y of the workspace; bias and epilogue belong to splitk_reduce_kernel
+  GemmArgs a = a_in;
+  const bool split = gridDim.y > 1;
+  if (split) {
+    a.y = TV{a_in.splitk_ws + (long)blockIdx.y * a_in.B * a_in.M * a_in.P, (long)a_in.M * a_in.P};
+    a.bias = nullptr;
+  }
   const int per_img = tiles_m * tiles_n;
   int id = xcd_remap(blockIdx.x, gridDim.x);
   const int b = id / per_img;
@@ -264,7 +273,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
   const float* __restrict__ wt = a.wt + (long)b * a.wt_bs;
   const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
   const int K = a.K, P = a.P;
-  const int nk = (K + BK - 1) / BK;
+  const int kt0 = (int)blockIdx.y * kt_per_split;
+  const int nk = min((K + BK - 1) / BK, kt0 + kt_per_split);
 
   // ---- per-slot loader state ----------------------------------------------------------------
   int x_row[XS], x_col[XS];
@@ -395,13 +405,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
 
   float4 xr[XS], wr[WS];
 #pragma unroll
-  for (int i = 0; i < XS; ++i) xr[i] = load_x(0, i);
+  for (int i = 0; i < XS; ++i) xr[i] = load_x(kt0, i);
 #pragma unroll
-  for (int i = 0; i < WS; ++i) wr[i] = load_w(0, i);
-  store_tiles(0, xr, wr);
+  for (int i = 0; i < WS; ++i) wr[i] = load_w(kt0, i);
+  store_tiles(kt0 & 1, xr, wr);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {
 #pragma unroll
@@ -457,6 +467,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
   };
   // only the loader/epilogue pairs the networks use are instantiated
   const int epi = a.epi;
+  if (split) {
+    run_epilogue(std::integral_constant<int, EP_STORE>{});
+    return;
+  }
   if constexpr (LOADER == LD_GATHER) {
     run_epilogue(std::integral_constant<int, EP_AV_INTRA>{});
   } else if constexpr (LOADER == LD_LN) {
@@ -1354,14 +1368,58 @@ static void launch_xs_bn(const GemmArgs& a, int loader, bool vec, hipStream_t s)
     launch_xs<BN, 1>(a, loader, vec, s);
 }
 
+// Sums the split-K slabs in slab order (deterministic) and applies bias + epilogue.  One thread per output
+// element; consecutive threads take consecutive pixels.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a, const int splits) {
+  const long n = (long)a.B * a.M * a.P;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int p = (int)(e % a.P);
+  const long bm = e / a.P;
+  const int m = (int)(bm % a.M), b = (int)(bm / a.M);
+  float v = 0.f;
+  for (int sp = 0; sp < splits; ++sp) v += a.splitk_ws[(long)sp * n + e];
+  if (a.bias) v += a.bias[(long)b * a.bias_bs + m];
+  float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
+  const long at = (long)m * a.P + p;
+  switch (a.epi) {
+    case EP_RESID: yb[at] = v + a.r.p[(long)b * a.r.bs + at]; break;
+    case EP_GELU_MUL: yb[at] = gelu_erf(v) * a.r.p[(long)b * a.r.bs + at]; break;
+    case EP_GELU: yb[at] = gelu_erf(v); break;
+    case EP_LEAKY: yb[at] = v > 0.f ? v : 0.01f * v; break;
+    case EP_UNSHUFFLE: {
+      const int py = p / a.W, px = p - py * a.W;
+      yb[(long)(4 * m + 2 * (py & 1) + (px & 1)) * (a.P >> 2) + (long)(py >> 1) * (a.W >> 1) + (px >> 1)] = v;
+      break;
+    }
+    case EP_SHUFFLE: {
+      const int py = p / a.W, px = p - py * a.W;
+      yb[(long)(m >> 2) * (4L * a.P) + (long)(2 * py + ((m >> 1) & 1)) * (2 * a.W) + 2 * px + (m & 1)] = v;
+      break;
+    }
+    default: yb[at] = v;
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_tile(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.P + BN - 1) / BN;
-  const dim3 grid((unsigned)(tiles_m * tiles_n * a.B)), block(64 * WAVES_M * WAVES_N);
+  // split-K: an underfilled grid with a long reduction is cut so that about two workgroups per CU exist
+  // (at least 4 chunks of 16 per slab; the slabs must fit the caller's workspace)
+  const long blocks = (long)tiles_m * tiles_n * a.B;
+  const int nk = (a.K + GEMM_BK - 1) / GEMM_BK;
+  int splits = 1;
+  if (a.splitk_ws && loader != LD_GATHER && blocks < 256 && nk >= 8) {
+    splits = (int)std::min<long>(std::min<long>(nk / 4, (512 + blocks - 1) / blocks), 32);
+    while (splits > 1 && (size_t)splits * a.B * a.M * a.P > a.splitk_floats) --splits;
+  }
+  const int kt_per = (nk + splits - 1) / splits;
+  splits = (nk + kt_per - 1) / kt_per;
+  const dim3 grid((unsigned)blocks, (unsigned)splits), block(64 * WAVES_M * WAVES_N);
 #define JIRF_GEMM_CASE(LD, V)                                                                   \
   hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, TM, TN, LD, V>), grid, block, 0, s, a, tiles_m, \
-                     tiles_n)
+                     tiles_n, kt_per)
   switch (loader) {
     case LD_PLAIN:
       if (vec) JIRF_GEMM_CASE(LD_PLAIN, true); else JIRF_GEMM_CASE(LD_PLAIN, false);
@@ -1380,6 +1438,11 @@ static void launch_tile(const GemmArgs& a, int loader, bool vec, hipStream_t s) 
   }
 #undef JIRF_GEMM_CASE
   JIRF_HIP_CHECK(hipGetLastError());
+  if (splits > 1) {
+    const long n = (long)a.B * a.M * a.P;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, splits);
+    JIRF_HIP_CHECK(hipGetLastError());
+  }
 }
 
 void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {

@@ -269,6 +269,7 @@ class AstNet final : public Net {
   }
 
   void carve(Arena& a, int B, int H, int W) {
+    splitk_ = a.floats(SPLITK_WS_FLOATS);   // slabs of split-K GEMMs (launch_gemm)
     const size_t nB = B, E = E_;
     size_t P[5];
     for (int l = 0; l < 5; ++l) P[l] = (size_t)(H >> l) * (W >> l);
@@ -291,6 +292,7 @@ class AstNet final : public Net {
 
   void gemm(const PackedW& w, TV x, TV y, int B, int P, int epi, TV r, hipStream_t s) {
     GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.B = B; g.M = w.M; g.K = w.K; g.P = P; g.Mpad = w.Mpad;
     g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r; g.imgs_per_group = 1;
     launch_gemm(g, LD_PLAIN, s);
@@ -298,6 +300,7 @@ class AstNet final : public Net {
   void conv(const PackedW& w, TV x, TV y, int B, int Hin, int Win, int ks, int stride, int pad, int epi, TV r,
             hipStream_t s) {
     GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.H = (Hin + 2 * pad - ks) / stride + 1;
     g.W = (Win + 2 * pad - ks) / stride + 1;
     g.B = B; g.M = w.M; g.K = w.K; g.P = g.H * g.W; g.Mpad = w.Mpad;
@@ -313,6 +316,7 @@ class AstNet final : public Net {
       // norm1 -> fused q|k|v projection -> window attention -> proj + shortcut
       if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
       GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
       g.B = B; g.M = 3 * C; g.K = C; g.P = P; g.Mpad = bl.qkv.Mpad; g.wt = bl.qkv.wt; g.bias = bl.qkv.bias;
       g.x = x; g.y = t1; g.epi = EP_STORE; g.imgs_per_group = 1;
       g.mu = mu_; g.rstd = rstd_; g.lnw = nullptr; g.lnb = nullptr; g.ln_center = 1;
@@ -344,6 +348,7 @@ class AstNet final : public Net {
     conv(bl.pconv, tv_chan(t2, 0, P), tv_chan(t2, C, P), B, H, W, 3, 1, 1, EP_STORE, TV{}, s);
     {
       GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
       g.B = B; g.M = 2 * h; g.K = C; g.P = P; g.Mpad = bl.lin1.Mpad; g.wt = bl.lin1.wt; g.bias = bl.lin1.bias;
       g.x = tv_chan(t2, 0, P); g.x2 = tv_chan(t2, C, P); g.k_split = C / 4;
       g.y = t1; g.epi = EP_GELU; g.imgs_per_group = 1;
@@ -380,6 +385,7 @@ class AstNet final : public Net {
     for (int i = 0; i < 4; ++i) {
       const int l = 3 - i;  // upsample_i: level l+1 -> level l, into the lower half of cat_l
       GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
       g.B = B; g.M = up_[i].M; g.K = up_[i].K; g.P = (int)P[l + 1]; g.Mpad = up_[i].Mpad;
       g.wt = up_[i].wt; g.bias = up_[i].bias; g.x = below; g.y = cat[l];
       g.epi = EP_SHUFFLE; g.H = Hl[l + 1]; g.W = Wl[l + 1]; g.imgs_per_group = 1;
@@ -399,6 +405,7 @@ class AstNet final : public Net {
   std::vector<AstLayer> layers_;
   WeightPool pool_;
   PackedW in_proj_, out_proj_, down_[4], up_[4];
+  float* splitk_ = nullptr;
   DeviceBuffer arena_;
   int pB_ = 0, pH_ = 0, pW_ = 0;
   float *in_ = nullptr, *outb_ = nullptr, *cat_[4] = {nullptr, nullptr, nullptr, nullptr}, *x4_ = nullptr;

@@ -352,6 +352,7 @@ class FproNet final : public Net {
   }
 
   void carve(Arena& a, int B, int H, int W) {
+    splitk_ = a.floats(SPLITK_WS_FLOATS);   // slabs of split-K GEMMs (launch_gemm)
     const size_t d = dim_, P1 = (size_t)H * W, P2 = P1 / 4, P3 = P1 / 16, nB = B;
     in_ = a.floats(nB * inp_ch_ * P1);
     outb_ = a.floats(nB * out_ch_ * P1);
@@ -398,6 +399,7 @@ class FproNet final : public Net {
   void gemm(const PackedW& w, TV x, TV y, int B, int P, int epi, TV r, hipStream_t s, int loader = LD_PLAIN,
             const float* lnw = nullptr, const float* lnb = nullptr) {
     GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.B = B; g.M = w.M; g.K = w.K; g.P = P; g.Mpad = w.Mpad;
     g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r; g.imgs_per_group = 1;
     if (loader == LD_LN) {
@@ -407,6 +409,7 @@ class FproNet final : public Net {
   }
   void conv3(const PackedW& w, TV x, TV y, int B, int H, int W, int epi, TV r, hipStream_t s) {
     GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.B = B; g.M = w.M; g.K = w.K; g.P = H * W; g.Mpad = w.Mpad;
     g.wt = w.wt; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r;
     g.H = H; g.W = W; g.Cin = w.Cin; g.imgs_per_group = 1;
@@ -425,7 +428,8 @@ class FproNet final : public Net {
       head_attn_scratch_carve(B, C, P, head_attn_splits(B, C, P), attn_scratch_, &sc);
       launch_head_attention(B, C, P, bl.heads, tv_chan(t2, 0, P), tv_chan(t2, C, P), bl.temperature, nullptr,
                             nullptr, sc, s, 1e-12f);
-      GemmArgs g{};  // attention * V: block-diagonal per-image "weight"
+      GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;  // attention * V: block-diagonal per-image "weight"
       g.B = B; g.M = C; g.K = C; g.P = P;
       g.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
       g.wt = sc.att_t;
@@ -465,6 +469,7 @@ class FproNet final : public Net {
     launch_channel_mean(low, lmean_, B, d, (long)P, s);
     launch_prompt_low(lmean_, (float)P, pm.body_w, pm.body_b, pm.w00, 1.0f / (float)P, pm.M, pm.b0, pbias_, B, d, C, s);
     GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.B = B; g.M = C; g.K = C; g.P = P; g.Mpad = pm.fuse_hi.Mpad;
     g.wt = pm.fuse_hi.wt; g.bias = pbias_; g.bias_bs = C;
     g.x = att; g.y = x; g.r = x; g.epi = EP_RESID; g.imgs_per_group = 1;
@@ -522,6 +527,7 @@ class FproNet final : public Net {
   DynFilterW dyn_{};
   WeightPool pool_;
   PackedW patch_, down12_, down23_, up32_, up21_, red2_, skip_, out_;
+  float* splitk_ = nullptr;
   DeviceBuffer arena_;
   int pB_ = 0, pH_ = 0, pW_ = 0;
   float *in_ = nullptr, *outb_ = nullptr, *cat1_ = nullptr, *cat2_ = nullptr, *x2_ = nullptr, *x3_ = nullptr;

@@ -388,6 +388,7 @@ class HintNet final : public Net {
 
   // ---- arena -----------------------------------------------------------------------------------
   void carve(Arena& a, int B, int H, int W, int mode) {
+    splitk_ = a.floats(SPLITK_WS_FLOATS);   // slabs of split-K GEMMs (launch_gemm)
     const size_t d = dim_, P1 = (size_t)H * W, P2 = P1 / 4, P3 = P1 / 16, P4 = P1 / 64;
     const size_t nB = B;
     in_ = a.floats(nB * inp_ch_ * P1);
@@ -434,6 +435,7 @@ class HintNet final : public Net {
   void gemm(const PackedW& w, TV x, TV y, int B, int P, int epi, TV r, hipStream_t s,
             int loader = LD_PLAIN, const LNW* ln = nullptr) {
     GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.B = B; g.M = w.M; g.K = w.K; g.P = P; g.Mpad = w.Mpad;
     g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.wt_bs = 0; g.bias = w.bias;
     g.x = x; g.y = y; g.epi = epi; g.r = r;
@@ -446,6 +448,7 @@ class HintNet final : public Net {
   }
   void conv3(const PackedW& w, TV x, TV y, int B, int H, int W, int epi, TV r, hipStream_t s) {
     GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.B = B; g.M = w.M; g.K = w.K; g.P = H * W; g.Mpad = w.Mpad;
     g.wt = w.wt; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r;
     g.H = H; g.W = W; g.Cin = w.Cin; g.imgs_per_group = 1;
@@ -473,6 +476,7 @@ class HintNet final : public Net {
       cache_cur_ = cout; cache_c_ = C; cache_g_ = sh.G; cache_valid_ = true;
       // attention * V with the sorted channel order, fused with s = out + q^ + k^
       GemmArgs g{};
+    g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
       g.B = B; g.M = C; g.K = C; g.P = P;
       g.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
       g.wt = sc.att_t;
@@ -585,6 +589,7 @@ class HintNet final : public Net {
   WeightPool pool_;
   PackedW patch_, down12_, down23_, down34_, up43_, up32_, up21_, red3_, red2_, skip_, out_;
 
+  float* splitk_ = nullptr;
   DeviceBuffer arena_, cache_store_;
   int pB_ = 0, pH_ = 0, pW_ = 0, pmode_ = -1;
   float *in_ = nullptr, *outb_ = nullptr, *cat1_ = nullptr, *cat2_ = nullptr, *cat3_ = nullptr;
