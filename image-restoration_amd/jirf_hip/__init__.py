@@ -60,6 +60,14 @@ SIGNATURES = {
     "jirf_op_conv1x1": (_i, [_fp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "jirf_op_ln_conv1x1": (_i, [_fp, _fp, _fp, _i, _vp, _fp, _i, _i, _i, _i, _vp]),
     "jirf_op_ln_conv1x1_static": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "jirf_train_smooth_l1": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, C.POINTER(C.c_double), _vp]),
+    "jirf_train_sumsq": (_i, [_fp, C.c_long, _vp, C.POINTER(C.c_double), _vp]),
+    "jirf_train_adam_step": (_i, [_fp, _fp, _fp, _fp, C.c_long, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, _i, _i, _vp]),
+    "jirf_train_linear_bwd_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_gelu_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "jirf_train_dwconv3x3_bwd_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_conv3x3": (_i, [_fp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_dwconv3x3": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

@@ -213,6 +213,43 @@ int jirf_op_psnr_work_doubles(void);
 int jirf_op_psnr_stats(const float* a, const float* b, int C, int H, int W, int crop_border, int quantise, int y_channel,
                        int blue_plane, double* work, void* stream);
 
+/* ---- training step (device side, as far as it is built): the loss, the optimiser update and the
+ *      backward of the operators that carry most of AST's parameters.  Raw device pointers, fp32, planar
+ *      [B][C][P].  Reference: ImageCleanModel.optimize_parameters, basicsr/models/image_restoration_model.py:235-276. */
+
+/* Pixel loss of the shipped configurations: "L1Loss" is nn.smooth_l1_loss with mean reduction
+ * (basicsr/models/losses/losses.py:12-14,44-52).  *loss_host = loss_weight * mean(l); grad (or NULL) receives
+ * d loss / d pred = loss_weight * clamp(pred - target, -1, 1) / n.  Synchronises `stream`. */
+int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, long n, float loss_weight,
+                         double* loss_host, void* stream);
+/* Sum of squares of a flat buffer in double (the norm of Optimizer.clip_grad_norm,
+ * image_restoration_model.py:269-270), to device and / or host memory.  Synchronises `stream`. */
+int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, void* stream);
+/* Gradient clip (max_norm > 0: g *= min(max_norm / (sqrt(*sumsq_dev) + 1e-6), 1)) fused with one Adam step
+ * on flat buffers p, g, m, v of n floats; step counts from 1.  torch_form 0: Jittor's update
+ * p -= m * lr * sqrt(1 - b1^t) / (1 - b0^t) / (sqrt(v) + eps) (what optimizer_g.step() runs,
+ * image_restoration_model.py:215,271); 1: torch.optim.Adam's placement of eps.  Asynchronous on `stream`. */
+int jirf_train_adam_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq_dev, float max_norm,
+                         float lr, float beta0, float beta1, float eps, int step, int torch_form, void* stream);
+/* Linear / 1x1 convolution y = W x (+ b): dw [M,K] (+)= sum_{b,p} dy[b,:,p] x[b,:,p]^T, db [M] (+)= sum dy
+ * (db may be NULL).  nn.Linear of ast_arch.py:100-101,171,456-474.  P % 4 == 0.  The input gradient is the
+ * forward kernel on the transposed weights (jirf_op_conv1x1 with w^T). */
+int jirf_train_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int B, int M, int K, int P,
+                                 int accumulate, void* stream);
+/* Per-pixel LayerNorm over channels (ast_arch.py:694,718,743 nn.LayerNorm = kind 1; kind 2 = the BiasFree form of
+ * hint_arch.py:98-117): dx [B,C,P], dw [C], db [C] (kind 1) from x, dy and the weight w. */
+int jirf_train_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int B,
+                             int C, int P, int kind, int accumulate, void* stream);
+/* mode 0: dx = dy * gelu'(pre), [B,C,P] (the GELU after linear1, ast_arch.py:384,456).
+ * mode 1: the FRFN gate y = gelu(a) * b (ast_arch.py:507-510) with a = pre [B,C,P] and b = x2 the two halves of
+ * one [B,2C,P] tensor: dx [B,2C,P] = (dy * b * gelu'(a), dy * gelu(a)). */
+int jirf_train_gelu_bwd(const float* pre, const float* x2, const float* dy, float* dx, int B, int C, int P, int mode,
+                        void* stream);
+/* Depthwise 3x3 (zero pad 1, ast_arch.py:458-466): dw [C,1,3,3] and db [C] (or NULL).  The input gradient is
+ * the forward kernel with the taps reversed (jirf_op_dwconv3x3). */
+int jirf_train_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db, int B, int C, int H, int W,
+                                    int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
