@@ -255,6 +255,7 @@ struct WinAttnArgs {
   const float* table;        // relative_position_bias_table [225][heads]
   float scale;               // head_dim^-0.5
   float w_softmax, w_relu2;  // softmax([w0, w1]) mixing weights
+  const float* w_dev = nullptr;  // training: the raw [w0, w1] in device memory (they change every step); overrides the two above
 };
 void launch_window_attention(const WinAttnArgs& a, hipStream_t s);
 

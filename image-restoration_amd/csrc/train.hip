@@ -9,6 +9,7 @@
 // reduction is two-stage with a fixed order (no atomics), so a step is reproducible.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 #include "runtime.h"
 
@@ -101,13 +102,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // 8 k-steps of v_mfma_f32_32x32x2_f32 on a 2 x 2 tile grid follow; no workgroup barrier in the loop.  The
 // four waves' sums are added through LDS in wave order and written to slab [blockIdx.z]; a second kernel
 // adds the slabs in order.  db[o] = sum dY rides along (k-tile 0 only).
+// CONV: the same contraction for a k x k convolution, dW[o][c][ky][kx] = sum dY[b][o][oy][ox] X[b][c][oy s - pad + ky]
+// [ox s - pad + kx]: row k = c * ks^2 + ky * ks + kx of the "X" operand is gathered from the input plane
+// (zero outside it), so the result comes out in the reference's [Cout][Cin][ks][ks] layout.
 constexpr int NT_T = 64, NT_PX = 16, NT_LD = NT_PX + 1;
 constexpr int NT_LPR = NT_PX / 4, NT_RPI = 64 / NT_LPR, NT_U = NT_T / NT_RPI;   // loader: lanes per row, rows per instruction
 
+struct ConvGeom {
+  int ks, stride, pad, Hin, Win, Wout;
+};
+
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restrict__ dy, long dy_bs,
                                                            const float* __restrict__ x, long x_bs,
                                                            float* __restrict__ part, double* __restrict__ dbpart,
-                                                           int B, int M, int K, int P, int chunks_per_slab) {
+                                                           int B, int M, int K, int P, int chunks_per_slab,
+                                                           ConvGeom cg) {
   __shared__ float lds[4][2][NT_T * NT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -137,7 +147,23 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restri
       const int row = lr + NT_RPI * u;
       const int pa = min(p0 + lc, P - 4);   // clamped address; the tail is zeroed below
       va[u] = *reinterpret_cast<const float4*>(dyb + (long)min(m0 + row, M - 1) * P + pa);
-      vb[u] = *reinterpret_cast<const float4*>(xb + (long)min(k0 + row, K - 1) * P + pa);
+      if constexpr (!CONV) {
+        vb[u] = *reinterpret_cast<const float4*>(xb + (long)min(k0 + row, K - 1) * P + pa);
+      } else {
+        const int k = min(k0 + row, K - 1), taps = cg.ks * cg.ks;
+        const int ch = k / taps, t = k - ch * taps, ky = t / cg.ks, kx = t - ky * cg.ks;
+        const float* __restrict__ plane = xb + (long)ch * cg.Hin * cg.Win;
+        float g4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = pa + j, oy = p / cg.Wout, ox = p - oy * cg.Wout;
+          const int sy = oy * cg.stride - cg.pad + ky, sx = ox * cg.stride - cg.pad + kx;
+          const bool in = sy >= 0 && sy < cg.Hin && sx >= 0 && sx < cg.Win;
+          const float v = plane[in ? sy * cg.Win + sx : 0];
+          g4[j] = in ? v : 0.f;
+        }
+        vb[u] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < NT_U; ++u) {
@@ -231,9 +257,11 @@ __global__ __launch_bounds__(256) void reduce_parts_d_kernel(const double* __res
 // dw / db partial sums per workgroup: part_w / part_b [gridDim.x * B... ][C], reduced by reduce_parts_d_kernel.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long x_bs,
                                                             const float* __restrict__ dy, long dy_bs,
-                                                            const float* __restrict__ w, float* __restrict__ dx,
-                                                            long dx_bs, double* __restrict__ part_w,
-                                                            double* __restrict__ part_b, int C, int P, int with_bias) {
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ add, long add_bs,
+                                                            float* __restrict__ dx, long dx_bs,
+                                                            double* __restrict__ part_w, double* __restrict__ part_b,
+                                                            int C, int P, int with_bias) {
   extern __shared__ double ln_red[];   // [256]
   const int b = blockIdx.y;
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -259,6 +287,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   s1 /= (float)C;
   s2 /= (float)C;
   float* __restrict__ dxb = dx + (long)b * dx_bs + (on ? p : 0);
+  const float* __restrict__ adb = add ? add + (long)b * add_bs + (on ? p : 0) : nullptr;   // + gradient of the shortcut
   const long slot = ((long)blockIdx.y * gridDim.x + blockIdx.x) * C;
   for (int c = 0; c < C; ++c) {
     const float xv = xb[(long)c * P], dyv = gb[(long)c * P];
@@ -267,6 +296,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float o;
     if (with_bias) o = rs * (g - s1 - nh * s2);
     else o = rs * g - (xv - mu) * rs * rs * rs * s2;
+    if (adb) o += adb[(long)c * P];
     if (on) dxb[(long)c * P] = o;
     // parameter gradients: dw[c] = sum dy n, db[c] = sum dy  (n = nhat or x rs)
     const double tw = block_sum_d(on ? (double)dyv * (with_bias ? nh : xv * rs) : 0.0, ln_red);
@@ -278,25 +308,70 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
-// ---- elementwise backward pieces of the token MLPs ---------------------------------------------------------
-// mode 0: dx = dy * gelu'(pre)                                  (Linear + GELU: linear1 of FRFN / LeFF / Mlp)
-// mode 1: FRFN gate y = gelu(a) * b with a = pre [first h channels], b = x2 [h channels]:
-//         da = dy * b * gelu'(a)  -> dx[0:h],   db = dy * gelu(a)  -> dx[h:2h]
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ x2,
-                                                       const float* __restrict__ dy, float* __restrict__ dx, long n_img,
-                                                       long pre_bs, long x2_bs, long dy_bs, long dx_bs, long half_off,
+// ---- elementwise pieces of the token MLPs -------------------------------------------------------------------
+// One image = n_img contiguous floats at pointer + b * batch stride (a channel slice of a wider tensor is a
+// pointer offset plus that tensor's batch stride).
+// forward   mode 0: y = gelu(pre)                    (after linear1, ast_arch.py:384,456; after the depthwise 3x3 of LeFF)
+//           mode 1: y = gelu(pre) * x2               (the FRFN gate, ast_arch.py:507-510)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ pre, long pre_bs,
+                                                       const float* __restrict__ x2, long x2_bs, float* __restrict__ y,
+                                                       long y_bs, long n_img, int mode) {
+  const int b = blockIdx.y;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_img; i += (long)gridDim.x * 256) {
+    const float a = gelu_f(pre[(long)b * pre_bs + i]);
+    y[(long)b * y_bs + i] = mode ? a * x2[(long)b * x2_bs + i] : a;
+  }
+}
+// backward  mode 0: dxa = dy * gelu'(pre)
+//           mode 1: y = gelu(a) * b with a = pre, b = x2:  dxa = dy * b * gelu'(a),  dxb = dy * gelu(a)
+//           mode 2: LeakyReLU(0.01) (ast_arch.py:563 input_proj), pre = the activation's OUTPUT (same sign as its
+//                   input): dxa = dy * (pre > 0 ? 1 : 0.01)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, long pre_bs,
+                                                       const float* __restrict__ x2, long x2_bs,
+                                                       const float* __restrict__ dy, long dy_bs, float* __restrict__ dxa,
+                                                       long dxa_bs, float* __restrict__ dxb, long dxb_bs, long n_img,
                                                        int mode) {
   const int b = blockIdx.y;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_img; i += (long)gridDim.x * 256) {
     const float a = pre[(long)b * pre_bs + i], g = dy[(long)b * dy_bs + i];
     if (mode == 0) {
-      dx[(long)b * dx_bs + i] = g * gelu_grad_f(a);
-    } else {
+      dxa[(long)b * dxa_bs + i] = g * gelu_grad_f(a);
+    } else if (mode == 1) {
       const float bv = x2[(long)b * x2_bs + i];
-      dx[(long)b * dx_bs + i] = g * bv * gelu_grad_f(a);
-      dx[(long)b * dx_bs + half_off + i] = g * gelu_f(a);
+      dxa[(long)b * dxa_bs + i] = g * bv * gelu_grad_f(a);
+      dxb[(long)b * dxb_bs + i] = g * gelu_f(a);
+    } else {
+      dxa[(long)b * dxa_bs + i] = a > 0.f ? g : 0.01f * g;
     }
   }
+}
+// y = a (+ b): the copies of the concatenations and the sums of gradients that meet at a shortcut
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, long a_bs, const float* __restrict__ b2,
+                                                  long b_bs, float* __restrict__ y, long y_bs, long n_img) {
+  const int b = blockIdx.y;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_img; i += (long)gridDim.x * 256) {
+    float v = a[(long)b * a_bs + i];
+    if (b2) v += b2[(long)b * b_bs + i];
+    y[(long)b * y_bs + i] = v;
+  }
+}
+// out[c] (+)= sum_{b,p} x[b][c][p] (the bias gradient of the transposed convolution): one workgroup per channel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out,
+                                                          int B, long P, int accumulate) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* __restrict__ xp = x + (long)b * x_bs + (long)c * P;
+    for (long i = threadIdx.x; i < P; i += 256) acc += xp[i];
+  }
+  const double t = block_sum_d(acc, red);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)t : (float)t;
+}
+// w [C][9] -> taps reversed (the depthwise data gradient is the forward kernel on these)
+__global__ void flip9_kernel(const float* __restrict__ w, float* __restrict__ out, int C) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < C * 9) out[e] = w[(e / 9) * 9 + 8 - e % 9];
 }
 
 // ---- depthwise 3x3, weight and bias gradients -------------------------------------------------------------
@@ -340,6 +415,260 @@ __global__ __launch_bounds__(256) void dwconv_dw_reduce_kernel(const double* __r
   if (dst) *dst = accumulate ? *dst + (float)s : (float)s;
 }
 
+
+// ---- weights of the training GEMMs, packed on the device -----------------------------------------------------
+// The forward GEMM family reads K-major packed weights wt[k][o] (k rows padded to 16, row length to 128).
+// In training the weights live in a flat device buffer in the reference's layouts and change every step, so
+// every call packs what it needs: the forward operand, or the operand of the data gradient.
+//   kind 0  forward convolution           w [M][Cin][taps]:            wt[tap Cin + c][o] = w[o][c][tap]
+//   kind 1  data gradient, stride 1       w [Cin][M][taps] (forward):  wt[tap Cin + c][o] = w[c][o][taps - 1 - tap]
+//   kind 2  ConvTranspose2d(2, stride 2)  w [Cin][M / 4][2][2]:        wt[c][o] = w[c][o]            (o = 4 co + tap)
+//   kind 4  data gradient of Conv2d(4, stride 2, pad 1), forward w [Cin][M / 4][4][4]: as a 3 x 3 convolution over
+//           the gradient plane whose row o = 4 ci + 2 a + b is output pixel (2 i + a, 2 j + b):
+//           wt[tap3 Cin + c][o] = w[c][ci][a + 1 - 2 dy][b + 1 - 2 dx] where that tap exists (tap3 = 3 (dy + 1) + dx + 1)
+__global__ __launch_bounds__(256) void pack_train_kernel(const float* __restrict__ w, float* __restrict__ wt, int kind,
+                                                         int M, int Cin, int taps, int K, int Kp, int Mp) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)Kp * Mp) return;
+  const int k = (int)(e / Mp), o = (int)(e - (long)k * Mp);
+  float v = 0.f;
+  if (k < K && o < M) {
+    const int tap = k / Cin, c = k - tap * Cin;
+    if (kind == 0) v = w[((long)o * Cin + c) * taps + tap];
+    else if (kind == 1) v = w[((long)c * M + o) * taps + (taps - 1 - tap)];
+    else if (kind == 2) v = w[(long)k * M + o];
+    else {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int ci = o >> 2, ky = ((o >> 1) & 1) + 1 - 2 * dy, kx = (o & 1) + 1 - 2 * dx;
+      if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) v = w[(((long)c * (M >> 2) + ci) * 4 + ky) * 4 + kx];
+    }
+  }
+  wt[e] = v;
+}
+__global__ void expand_bias4_kernel(const float* __restrict__ b, float* __restrict__ out, int M) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < M) out[e] = b[e >> 2];
+}
+
+// ---- sparse window attention, backward (ast_arch.py:275-318; forward kernel: win_attn.hip) ------------------
+// One wave per workgroup; workgroup (chunk, head) walks over the windows chunk, chunk + chunks, ... of its
+// head.  With lane n = query token n of the 8 x 8 window:
+//   S[n][m] = q_n k_m + bias + mask,  P0 = softmax_m S,  P1 = relu(S)^2,  A = w0 P0 + w1 P1,  O[n] = sum_m A[n][m] v_m
+//   dA[n][m] = dO_n v_m;   dS = w0 P0 (dA - sum_m dA P0) + 2 w1 relu(S) dA;   dq_n = scale sum_m dS[n][m] k_m
+//   dv_m = sum_n A[n][m] dO_n;   dk_m = sum_n dS[n][m] (scale q_n)            (through an LDS transpose, lane = m)
+//   d table[idx(n, m)][head] += dS[n][m];   d(w0, w1) += sum dA (P0, P1)
+// k comes from the (window, head) pair the reference's flattening pairs with this one (see the forward kernel),
+// and dk goes back there: the pairing is a bijection, so every gradient element has one writer.  The table
+// gradient is gathered from the transposed dS tile (lane = table entry: no two lanes ever add to one address),
+// kept with the mixing-weight sums per workgroup and added up afterwards in a fixed order.
+constexpr int WB_LD = 33, WB_TLD = 65;
+struct WinBwdArgs {
+  int B, C, H, W, heads, shift, coupled, chunks;
+  float scale;
+  const float *q, *k, *v, *dout;      // planar slices, batch strides below
+  long qkv_bs, dout_bs, dqkv_bs;
+  float *dq, *dk, *dv;
+  const float* table;                 // [225][heads]
+  const float* w2;                    // [2] raw mixing weights
+  double* part_table;                 // [heads][chunks][225]
+  double* part_w;                     // [heads][chunks][2]
+};
+
+__global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
+  __shared__ float Qs[64 * WB_LD], Ks[64 * WB_LD], Vs[64 * WB_LD], Gs[64 * WB_LD];
+  __shared__ float T[64 * WB_TLD];
+  __shared__ float ts[232];
+  const int lane = threadIdx.x, chunk = blockIdx.x, h = blockIdx.y;
+  const int H = a.H, W = a.W, heads = a.heads;
+  const int nwx = W >> 3, nW = (H >> 3) * nwx;
+  const long P = (long)H * W;
+  const int n_win = a.B * nW;
+  const float e0 = expf(a.w2[0]), e1 = expf(a.w2[1]);
+  const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
+  for (int i = lane; i < 232; i += 64) ts[i] = i < 225 ? a.table[i * heads + h] : 0.f;
+  float tacc[4] = {0.f, 0.f, 0.f, 0.f};   // table entries lane, lane + 64, lane + 128, lane + 192
+  const int ty = lane >> 3, tx = lane & 7;
+  double g0 = 0.0, g1 = 0.0;
+  for (int gw = chunk; gw < n_win; gw += a.chunks) {
+    const int img = gw / nW, w = gw - img * nW;
+    const int span = a.coupled ? a.B * nW : nW;
+    const int j = (a.coupled ? gw : w) * heads + h;
+    const int hk = j / span, bk = j - hk * span;
+    const int img_k = a.coupled ? bk / nW : img;
+    const int wk = a.coupled ? bk - img_k * nW : bk;
+    auto pixel = [&](int win) {
+      const int wy = win / nwx, wx = win - wy * nwx;
+      int y = wy * 8 + ty + a.shift, x = wx * 8 + tx + a.shift;
+      if (y >= H) y -= H;
+      if (x >= W) x -= W;
+      return (long)y * W + x;
+    };
+    const long pq = pixel(w), pk = pixel(wk);
+    const long oq = (long)img * a.qkv_bs + (long)(h * 32) * P + pq;
+    const long ok = (long)img_k * a.qkv_bs + (long)(hk * 32) * P + pk;
+    const long og = (long)img * a.dout_bs + (long)(h * 32) * P + pq;
+    __syncthreads();   // the previous window's tiles are no longer read
+#pragma unroll 8
+    for (int e = 0; e < 32; ++e) {
+      Qs[lane * WB_LD + e] = a.q[oq + (long)e * P] * a.scale;
+      Ks[lane * WB_LD + e] = a.k[ok + (long)e * P];
+      Vs[lane * WB_LD + e] = a.v[oq + (long)e * P];
+      Gs[lane * WB_LD + e] = a.dout[og + (long)e * P];
+    }
+    int rid = 0;
+    if (a.shift) {
+      const int wy = w / nwx, wx = w - wy * nwx;
+      const int sy = wy * 8 + ty, sx = wx * 8 + tx;
+      const int rh = sy < H - 8 ? 0 : (sy < H - a.shift ? 1 : 2);
+      const int rw = sx < W - 8 ? 0 : (sx < W - a.shift ? 1 : 2);
+      rid = 3 * rh + rw;
+    }
+    __syncthreads();
+    float q[32], g[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      q[e] = Qs[lane * WB_LD + e];
+      g[e] = Gs[lane * WB_LD + e];
+    }
+    float sc[64], da[64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      float s = 0.f, d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        s = fmaf(q[e], Ks[m * WB_LD + e], s);
+        d = fmaf(g[e], Vs[m * WB_LD + e], d);
+      }
+      s += ts[(ty - (m >> 3) + 7) * 15 + (tx - (m & 7) + 7)];
+      if (a.shift) {
+        const int rid_m = __shfl(rid, m);
+        if (rid_m != rid) s += -100.0f;
+      }
+      sc[m] = s;
+      da[m] = d;
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 64; ++m) sum += expf(sc[m] - mx);
+    const float inv = 1.0f / sum;
+    float D = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      const float p0 = expf(sc[m] - mx) * inv, r = fmaxf(sc[m], 0.f);
+      D = fmaf(da[m], p0, D);
+      t1 = fmaf(da[m], r * r, t1);
+    }
+    g0 += D;
+    g1 += t1;
+    float dq[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) dq[e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+      const float p0 = expf(sc[m] - mx) * inv, r = fmaxf(sc[m], 0.f);
+      T[lane * WB_TLD + m] = w0 * p0 + w1 * r * r;                      // A[n][m]
+      const float ds = w0 * p0 * (da[m] - D) + 2.0f * w1 * r * da[m];
+      da[m] = ds;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dq[e] = fmaf(ds, Ks[m * WB_LD + e], dq[e]);
+    }
+    {
+      float* __restrict__ dqp = a.dq + (long)img * a.dqkv_bs + (long)(h * 32) * P + pq;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dqp[(long)e * P] = dq[e] * a.scale;
+    }
+    __syncthreads();
+    {   // lane = key token m: dv_m = sum_n A[n][m] dO_n
+      float dv[32];
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dv[e] = 0.f;
+      for (int n = 0; n < 64; ++n) {
+        const float av = T[n * WB_TLD + lane];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) dv[e] = fmaf(av, Gs[n * WB_LD + e], dv[e]);
+      }
+      float* __restrict__ dvp = a.dv + (long)img * a.dqkv_bs + (long)(h * 32) * P + pq;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dvp[(long)e * P] = dv[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 64; ++m) T[lane * WB_TLD + m] = da[m];          // dS[n][m]
+    __syncthreads();
+    // table entry i = (dy + 7) * 15 + (dx + 7) collects dS[n][m] of every pair with n - m = (dy, dx)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int i = lane + 64 * t4;
+      if (i < 225) {
+        const int dy = i / 15 - 7, dx = i % 15 - 7;
+        float sacc = 0.f;
+        for (int ny = max(0, dy); ny <= min(7, 7 + dy); ++ny)
+          for (int nx = max(0, dx); nx <= min(7, 7 + dx); ++nx)
+            sacc += T[(ny * 8 + nx) * WB_TLD + (ny - dy) * 8 + (nx - dx)];
+        tacc[t4] += sacc;
+      }
+    }
+    {   // lane = key token m: dk_m = sum_n dS[n][m] (scale q_n)
+      float dk[32];
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dk[e] = 0.f;
+      for (int n = 0; n < 64; ++n) {
+        const float sv = T[n * WB_TLD + lane];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) dk[e] = fmaf(sv, Qs[n * WB_LD + e], dk[e]);
+      }
+      float* __restrict__ dkp = a.dk + (long)img_k * a.dqkv_bs + (long)(hk * 32) * P + pk;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dkp[(long)e * P] = dk[e];
+    }
+  }
+  __syncthreads();
+  const long slot = (long)h * a.chunks + chunk;
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4)
+    if (lane + 64 * t4 < 225) a.part_table[slot * 225 + lane + 64 * t4] = (double)tacc[t4];
+  // the two sums over the wave, in lane order
+  __shared__ double wred[2][64];
+  wred[0][lane] = g0;
+  wred[1][lane] = g1;
+  __syncthreads();
+  if (lane < 2) {
+    double t = 0.0;
+    for (int i = 0; i < 64; ++i) t += wred[lane][i];
+    a.part_w[slot * 2 + lane] = t;
+  }
+}
+
+// dtable[i][h] (+)= sum_chunk part_table[h][chunk][i];  d(w) through the two-way softmax of the mixing weights
+__global__ __launch_bounds__(256) void win_attn_bwd_reduce_kernel(const double* __restrict__ part_table,
+                                                                  const double* __restrict__ part_w,
+                                                                  const float* __restrict__ w2, int heads, int chunks,
+                                                                  float* __restrict__ dtable, float* __restrict__ dw2,
+                                                                  int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < 225 * heads) {
+    const int i = e / heads, h = e - i * heads;
+    double t = 0.0;
+    for (int c = 0; c < chunks; ++c) t += part_table[((long)h * chunks + c) * 225 + i];
+    dtable[e] = accumulate ? dtable[e] + (float)t : (float)t;
+  }
+  if (e == 0) {
+    double G0 = 0.0, G1 = 0.0;
+    for (long s = 0; s < (long)heads * chunks; ++s) {
+      G0 += part_w[s * 2];
+      G1 += part_w[s * 2 + 1];
+    }
+    const double e0 = exp((double)w2[0]), e1 = exp((double)w2[1]);
+    const double s0 = e0 / (e0 + e1), s1 = e1 / (e0 + e1);
+    const double dot = G0 * s0 + G1 * s1;
+    const float d0 = (float)(s0 * (G0 - dot)), d1 = (float)(s1 * (G1 - dot));
+    dw2[0] = accumulate ? dw2[0] + d0 : d0;
+    dw2[1] = accumulate ? dw2[1] + d1 : d1;
+  }
+}
+
 template <typename F>
 int guarded_t(F&& f) {
   try {
@@ -350,6 +679,55 @@ int guarded_t(F&& f) {
     set_error("host allocation failed");
     return JIRF_ENOMEM;
   }
+}
+
+// Scratch of the training operators (packed weights, partial sums): one set of buffers per device, grown on
+// demand and kept until the process ends, so a step allocates nothing once the shapes have been seen.  All
+// training calls on one device share it and order their use through the stream: calls that overlap on one
+// device (two streams, two threads) race.
+enum { SC_PACK = 0, SC_PART_A = 1, SC_PART_B = 2, SC_SMALL = 3, SC_SLOTS = 4 };
+void* train_scratch(int slot, size_t bytes) {
+  static std::mutex mu;
+  static DeviceBuffer pool[64][SC_SLOTS];
+  int dev = 0;
+  JIRF_HIP_CHECK(hipGetDevice(&dev));
+  JIRF_REQUIRE(dev >= 0 && dev < 64, JIRF_EINVAL, "training scratch: device %d", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  DeviceBuffer& b = pool[dev][slot];
+  if (b.bytes < bytes) {
+    JIRF_HIP_CHECK(hipDeviceSynchronize());   // the old buffer may still be in use by queued kernels
+    b.ensure(bytes + bytes / 4);
+  }
+  return b.p;
+}
+
+inline long dense(long bs, long c, long p) { return bs ? bs : c * p; }
+
+void conv_dw_launch(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, float* db, int B, int M, int K,
+                    int P, const ConvGeom* cg, int accumulate, hipStream_t s) {
+  const int tm = (M + NT_T - 1) / NT_T, tk = (K + NT_T - 1) / NT_T;
+  const long chunks = (long)((P + NT_PX - 1) / NT_PX) * B;
+  // enough slabs to fill the chip, at least 16 chunks (4 per wave) each
+  int slabs = (int)std::max<long>(1, std::min<long>(chunks / 16, (1024 + tm * tk - 1) / (tm * tk)));
+  const int cps = (int)((chunks + slabs - 1) / slabs);
+  slabs = (int)((chunks + cps - 1) / cps);
+  float* part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float)));
+  double* dbpart = db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double))) : nullptr;
+  Scope sc(intern_label("train_dw M%d K%d P%d", M, K, P), 2.0 * M * (double)K * P * B,
+           4.0 * B * (double)P * (M + (cg ? K / (cg->ks * cg->ks) : K)), s);
+  if (cg)
+    hipLaunchKernelGGL(linear_dw_kernel<true>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart, B,
+                       M, K, P, cps, *cg);
+  else
+    hipLaunchKernelGGL(linear_dw_kernel<false>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart, B,
+                       M, K, P, cps, ConvGeom{});
+  const long n = (long)M * K;
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, n, slabs, dw,
+                     accumulate);
+  if (db)
+    hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dbpart, (long)M, slabs, db,
+                       accumulate);
+  JIRF_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace
@@ -365,9 +743,7 @@ int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, lo
     JIRF_REQUIRE(pred && target && n > 0 && loss_host, JIRF_EINVAL, "smooth_l1: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<long>(1024, (n + 255) / 256);
-    DeviceBuffer part;
-    part.ensure((size_t)(blocks + 1) * sizeof(double));
-    double* pd = static_cast<double*>(part.p);
+    double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double)));
     hipLaunchKernelGGL(smooth_l1_kernel, dim3(blocks), dim3(256), 0, s, pred, target, grad, n,
                        loss_weight / (float)n, pd);
     hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, pd + blocks);
@@ -385,15 +761,14 @@ int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, 
     JIRF_REQUIRE(x && n > 0 && (out_dev || out_host), JIRF_EINVAL, "sumsq: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<long>(1024, (n + 255) / 256);
-    DeviceBuffer part;
-    part.ensure((size_t)(blocks + 1) * sizeof(double));
-    double* pd = static_cast<double*>(part.p);
+    double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double)));
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, pd);
     hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, out_dev ? out_dev : pd + blocks);
     JIRF_HIP_CHECK(hipGetLastError());
-    if (out_host)
+    if (out_host) {
       JIRF_HIP_CHECK(hipMemcpyAsync(out_host, out_dev ? out_dev : pd + blocks, sizeof(double), hipMemcpyDeviceToHost, s));
-    JIRF_HIP_CHECK(hipStreamSynchronize(s));   // `part` is released on return
+      JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    }
     return JIRF_OK;
   });
 }
@@ -412,88 +787,265 @@ int jirf_train_adam_step(float* p, const float* g, float* m, float* v, long n, c
   });
 }
 
+int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const float* bias, const float* r, long r_bs,
+                    float* y, long y_bs, int B, int Cin, int Cout, int Hin, int Win, int ks, int stride, int pad,
+                    int epi, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, JIRF_EINVAL, "train_conv: bad arguments");
+    JIRF_REQUIRE(w_kind == JIRF_W_FWD || w_kind == JIRF_W_BWD_DATA || w_kind == JIRF_W_DECONV ||
+                     w_kind == JIRF_W_DOWN_BWD_DATA, JIRF_EINVAL, "train_conv: weight kind %d", w_kind);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GemmArgs g{};
+    int loader = LD_PLAIN, M = Cout, taps = 1, pk_cin = Cin;
+    g.B = B; g.imgs_per_group = 1; g.epi = epi;
+    if (w_kind == JIRF_W_DECONV) {
+      JIRF_REQUIRE(epi == 0 && !r, JIRF_EINVAL, "train_conv: the transposed convolution takes no epilogue");
+      M = 4 * Cout; g.K = Cin; g.P = Hin * Win; g.H = Hin; g.W = Win; g.epi = EP_SHUFFLE;
+    } else if (w_kind == JIRF_W_DOWN_BWD_DATA) {
+      JIRF_REQUIRE(epi == 0 && !r, JIRF_EINVAL, "train_conv: the strided data gradient takes no epilogue");
+      M = 4 * Cout; taps = 9; g.K = 9 * Cin; g.P = Hin * Win; g.H = Hin; g.W = Win; g.Hin = Hin; g.Win = Win;
+      g.Cin = Cin; g.ks = 3; g.stride = 1; g.pad = 1; g.epi = EP_SHUFFLE; loader = LD_CONV3;
+    } else {
+      JIRF_REQUIRE(ks >= 1 && ks <= 7 && stride >= 1 && pad >= 0, JIRF_EINVAL, "train_conv: geometry k%d s%d p%d", ks, stride, pad);
+      taps = ks * ks;
+      int p_eff = pad;
+      if (w_kind == JIRF_W_BWD_DATA) {
+        JIRF_REQUIRE(stride == 1 && pad <= ks - 1, JIRF_EINVAL, "train_conv: the data gradient form needs stride 1");
+        p_eff = ks - 1 - pad;
+      }
+      g.K = taps * Cin;
+      if (ks == 1 && stride == 1 && pad == 0) {
+        g.P = Hin * Win;
+      } else {
+        loader = LD_CONV3;
+        g.H = (Hin + 2 * p_eff - ks) / stride + 1;
+        g.W = (Win + 2 * p_eff - ks) / stride + 1;
+        g.P = g.H * g.W; g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.ks = ks; g.stride = stride; g.pad = p_eff;
+      }
+    }
+    (void)pk_cin;
+    const int Mp = (M + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD, Kp = (g.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+    float* wt = static_cast<float*>(train_scratch(SC_PACK, ((size_t)Kp * Mp + Mp) * sizeof(float)));
+    const int kind = w_kind == JIRF_W_FWD ? 0 : w_kind == JIRF_W_BWD_DATA ? 1 : w_kind == JIRF_W_DECONV ? 2 : 4;
+    hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)(((long)Kp * Mp + 255) / 256)), dim3(256), 0, s, w, wt, kind, M,
+                       Cin, taps, g.K, Kp, Mp);
+    const float* bias_use = bias;
+    if (bias && w_kind == JIRF_W_DECONV) {
+      float* b4 = wt + (size_t)Kp * Mp;
+      hipLaunchKernelGGL(expand_bias4_kernel, dim3((M + 255) / 256), dim3(256), 0, s, bias, b4, M);
+      bias_use = b4;
+    }
+    JIRF_HIP_CHECK(hipGetLastError());
+    g.M = M; g.Mpad = Mp; g.wt = wt; g.bias = bias_use;
+    const long Pin = (long)Hin * Win;
+    const long Pout = (g.epi == EP_SHUFFLE) ? 4L * g.P : g.P;
+    g.x = tv(const_cast<float*>(x), dense(x_bs, Cin, Pin));
+    g.y = tv(y, dense(y_bs, Cout, Pout));
+    if (r) g.r = tv(const_cast<float*>(r), dense(r_bs, Cout, Pout));
+    JIRF_REQUIRE((g.epi == EP_RESID || g.epi == EP_GELU_MUL) == (r != nullptr), JIRF_EINVAL,
+                 "train_conv: epilogue %d and the residual / gate operand do not match", epi);
+    launch_gemm(g, loader, s);
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_conv_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, float* db, int B,
+                               int M, int Cin, int Hout, int Wout, int Hin, int Win, int ks, int stride, int pad,
+                               int accumulate, void* stream) {
+  return guarded_t([&] {
+    const int P = Hout * Wout;
+    JIRF_REQUIRE(dy && x && dw && B > 0 && M > 0 && Cin > 0 && P >= 16 && P % 16 == 0 && ks >= 1 && stride >= 1 && pad >= 0,
+                 JIRF_EINVAL, "conv_bwd_weight: bad arguments (the output plane must be a multiple of 16 pixels)");
+    JIRF_REQUIRE((Hin + 2 * pad - ks) / stride + 1 == Hout && (Win + 2 * pad - ks) / stride + 1 == Wout, JIRF_EINVAL,
+                 "conv_bwd_weight: geometry out %dx%d in %dx%d k%d s%d p%d", Hout, Wout, Hin, Win, ks, stride, pad);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool plain = ks == 1 && stride == 1 && pad == 0;
+    ConvGeom cg{ks, stride, pad, Hin, Win, Wout};
+    JIRF_REQUIRE((dense(dy_bs, M, P) % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                     (!plain || ((dense(x_bs, Cin, P) % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)),
+                 JIRF_EINVAL, "conv_bwd_weight: operands must be 16-byte aligned");
+    conv_dw_launch(dy, dense(dy_bs, M, P), x, dense(x_bs, Cin, (long)Hin * Win), dw, db, B, M, Cin * ks * ks, P,
+                   plain ? nullptr : &cg, accumulate, s);
+    return JIRF_OK;
+  });
+}
+
 int jirf_train_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int B, int M, int K, int P,
                                  int accumulate, void* stream) {
   return guarded_t([&] {
     JIRF_REQUIRE(dy && x && dw && B > 0 && M > 0 && K > 0 && P >= 4 && P % 4 == 0, JIRF_EINVAL,
                  "linear_bwd_weight: bad arguments (P must be a multiple of 4)");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int tm = (M + NT_T - 1) / NT_T, tk = (K + NT_T - 1) / NT_T;
-    const long chunks = (long)((P + NT_PX - 1) / NT_PX) * B;
-    // enough slabs to fill the chip, at least 16 chunks (4 per wave) each
-    int slabs = (int)std::max<long>(1, std::min<long>(chunks / 16, (1024 + tm * tk - 1) / (tm * tk)));
-    const int cps = (int)((chunks + slabs - 1) / slabs);
-    slabs = (int)((chunks + cps - 1) / cps);
-    DeviceBuffer part, dbpart;
-    part.ensure((size_t)slabs * M * K * sizeof(float));
-    if (db) dbpart.ensure((size_t)slabs * M * sizeof(double));
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(tm, tk, slabs), dim3(256), 0, s, dy, (long)M * P, x, (long)K * P,
-                       static_cast<float*>(part.p), db ? static_cast<double*>(dbpart.p) : nullptr, B, M, K, P, cps);
-    const long n = (long)M * K;
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                       static_cast<const float*>(part.p), n, slabs, dw, accumulate);
-    if (db)
-      hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((M + 255) / 256), dim3(256), 0, s,
-                         static_cast<const double*>(dbpart.p), (long)M, slabs, db, accumulate);
-    JIRF_HIP_CHECK(hipGetLastError());
-    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    conv_dw_launch(dy, (long)M * P, x, (long)K * P, dw, db, B, M, K, P, nullptr, accumulate,
+                   static_cast<hipStream_t>(stream));
     return JIRF_OK;
   });
 }
 
-int jirf_train_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int B,
-                             int C, int P, int kind, int accumulate, void* stream) {
+int jirf_train_layernorm(const float* x, long x_bs, const float* w, const float* b, float* y, long y_bs, int B, int C,
+                         int P, int kind, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(x && w && y && B > 0 && C > 0 && P > 0 && (kind == 1 || kind == 2), JIRF_EINVAL, "train_layernorm: bad arguments");
+    launch_layernorm(tv(const_cast<float*>(x), dense(x_bs, C, P)), w, b, tv(y, dense(y_bs, C, P)), B, C, P, kind,
+                     static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_layernorm_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w, const float* add,
+                             long add_bs, float* dx, long dx_bs, float* dw, float* db, int B, int C, int P, int kind,
+                             int accumulate, void* stream) {
   return guarded_t([&] {
     JIRF_REQUIRE(x && dy && w && dx && dw && B > 0 && C > 0 && P > 0 && (kind == 1 || kind == 2), JIRF_EINVAL,
                  "layernorm_bwd: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = (P + 255) / 256;
     const int slots = gx * B;
-    DeviceBuffer pw, pb;
-    pw.ensure((size_t)slots * C * sizeof(double));
-    pb.ensure((size_t)slots * C * sizeof(double));
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(gx, B), dim3(256), 256 * sizeof(double), s, x, (long)C * P, dy,
-                       (long)C * P, w, dx, (long)C * P, static_cast<double*>(pw.p), static_cast<double*>(pb.p), C, P,
+    double* pw = static_cast<double*>(train_scratch(SC_PART_A, (size_t)slots * C * sizeof(double)));
+    double* pb = static_cast<double*>(train_scratch(SC_PART_B, (size_t)slots * C * sizeof(double)));
+    Scope sc(intern_label("train_layernorm_bwd C%d P%d", C, P), 12.0 * B * C * (double)P, 4.0 * B * C * (double)P * 7, s);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(gx, B), dim3(256), 256 * sizeof(double), s, x, dense(x_bs, C, P), dy,
+                       dense(dy_bs, C, P), w, add, dense(add_bs, C, P), dx, dense(dx_bs, C, P), pw, pb, C, P,
                        kind == 1 ? 1 : 0);
-    hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((C + 255) / 256), dim3(256), 0, s, static_cast<const double*>(pw.p),
-                       (long)C, slots, dw, accumulate);
+    hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((C + 255) / 256), dim3(256), 0, s, pw, (long)C, slots, dw, accumulate);
     if (db && kind == 1)
-      hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
-                         static_cast<const double*>(pb.p), (long)C, slots, db, accumulate);
+      hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((C + 255) / 256), dim3(256), 0, s, pb, (long)C, slots, db,
+                         accumulate);
     JIRF_HIP_CHECK(hipGetLastError());
-    JIRF_HIP_CHECK(hipStreamSynchronize(s));
     return JIRF_OK;
   });
 }
 
-int jirf_train_gelu_bwd(const float* pre, const float* x2, const float* dy, float* dx, int B, int C, int P, int mode,
-                        void* stream) {
+int jirf_train_gelu(const float* pre, long pre_bs, const float* x2, long x2_bs, float* y, long y_bs, int B, long n_img,
+                    int mode, void* stream) {
   return guarded_t([&] {
-    JIRF_REQUIRE(pre && dy && dx && B > 0 && C > 0 && P > 0 && (mode == 0 || (mode == 1 && x2)), JIRF_EINVAL,
-                 "gelu_bwd: bad arguments");
-    const long n_img = (long)C * P;
+    JIRF_REQUIRE(pre && y && B > 0 && n_img > 0 && (mode == 0 || (mode == 1 && x2)), JIRF_EINVAL, "train_gelu: bad arguments");
     const int gx = (int)std::min<long>(2048, (n_img + 255) / 256);
-    // mode 1: pre / x2 are the two halves [C][P] of one [2C][P] tensor per image, dx likewise
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(gx, B), dim3(256), 0, static_cast<hipStream_t>(stream), pre, x2, dy, dx,
-                       n_img, mode ? 2 * n_img : n_img, mode ? 2 * n_img : 0L, n_img, mode ? 2 * n_img : n_img, n_img, mode);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(intern_label("train_gelu n%ld", n_img), 10.0 * B * (double)n_img, 4.0 * B * (double)n_img * (2 + mode), s);
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(gx, B), dim3(256), 0, s, pre, pre_bs ? pre_bs : n_img, x2,
+                       x2_bs ? x2_bs : n_img, y, y_bs ? y_bs : n_img, n_img, mode);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });
 }
 
-int jirf_train_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db, int B, int C, int H, int W,
-                                    int accumulate, void* stream) {
+int jirf_train_gelu_bwd(const float* pre, long pre_bs, const float* x2, long x2_bs, const float* dy, long dy_bs,
+                        float* dxa, long dxa_bs, float* dxb, long dxb_bs, int B, long n_img, int mode, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(pre && dy && dxa && B > 0 && n_img > 0 && (mode == 0 || mode == 2 || (mode == 1 && x2 && dxb)), JIRF_EINVAL,
+                 "gelu_bwd: bad arguments");
+    const int gx = (int)std::min<long>(2048, (n_img + 255) / 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(intern_label("train_gelu_bwd n%ld", n_img), 20.0 * B * (double)n_img, 4.0 * B * (double)n_img * (3 + 2 * (mode == 1)), s);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(gx, B), dim3(256), 0, s, pre, pre_bs ? pre_bs : n_img, x2,
+                       x2_bs ? x2_bs : n_img, dy, dy_bs ? dy_bs : n_img, dxa, dxa_bs ? dxa_bs : n_img, dxb,
+                       dxb_bs ? dxb_bs : n_img, n_img, mode);
+    JIRF_HIP_CHECK(hipGetLastError());
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_add(const float* a, long a_bs, const float* b, long b_bs, float* y, long y_bs, int B, long n_img,
+                   void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(a && y && B > 0 && n_img > 0, JIRF_EINVAL, "train_add: bad arguments");
+    const int gx = (int)std::min<long>(2048, (n_img + 255) / 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(intern_label("train_add n%ld", n_img), 1.0 * B * (double)n_img, 4.0 * B * (double)n_img * (b ? 3 : 2), s);
+    hipLaunchKernelGGL(add_kernel, dim3(gx, B), dim3(256), 0, s, a, a_bs ? a_bs : n_img, b, b_bs ? b_bs : n_img, y,
+                       y_bs ? y_bs : n_img, n_img);
+    JIRF_HIP_CHECK(hipGetLastError());
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_channel_sum(const float* x, long x_bs, float* out, int B, int C, long P, int accumulate, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(x && out && B > 0 && C > 0 && P > 0, JIRF_EINVAL, "channel_sum: bad arguments");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       dense(x_bs, C, P), out, B, P, accumulate);
+    JIRF_HIP_CHECK(hipGetLastError());
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_dwconv3x3(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs, int B, int C,
+                         int H, int W, int flip, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(x && w && y && B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "train_dwconv3x3: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* wu = w;
+    if (flip) {
+      float* wf = static_cast<float*>(train_scratch(SC_SMALL, (size_t)C * 9 * sizeof(float)));
+      hipLaunchKernelGGL(flip9_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, w, wf, C);
+      JIRF_HIP_CHECK(hipGetLastError());
+      wu = wf;
+    }
+    const long P = (long)H * W;
+    launch_dwconv3x3(tv(const_cast<float*>(x), dense(x_bs, C, P)), wu, bias, tv(y, dense(y_bs, C, P)), B, C, H, W, 0, s);
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_dwconv3x3_bwd_weight(const float* x, long x_bs, const float* dy, long dy_bs, float* dw, float* db, int B,
+                                    int C, int H, int W, int accumulate, void* stream) {
   return guarded_t([&] {
     JIRF_REQUIRE(x && dy && dw && B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "dwconv3x3_bwd_weight: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DeviceBuffer part;
-    part.ensure((size_t)B * C * 10 * sizeof(double));
-    hipLaunchKernelGGL(dwconv_dw_kernel, dim3(C, B), dim3(256), 0, s, x, (long)C * H * W, dy, (long)C * H * W,
-                       static_cast<double*>(part.p), C, H, W);
-    hipLaunchKernelGGL(dwconv_dw_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s,
-                       static_cast<const double*>(part.p), B, C, dw, db, accumulate);
+    const long P = (long)H * W;
+    double* part = static_cast<double*>(train_scratch(SC_PART_A, (size_t)B * C * 10 * sizeof(double)));
+    Scope sc(intern_label("train_dwconv_dw C%d H%d W%d", C, H, W), 20.0 * B * C * (double)P, 8.0 * B * C * (double)P, s);
+    hipLaunchKernelGGL(dwconv_dw_kernel, dim3(C, B), dim3(256), 0, s, x, dense(x_bs, C, P), dy, dense(dy_bs, C, P), part,
+                       C, H, W);
+    hipLaunchKernelGGL(dwconv_dw_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, B, C, dw, db,
+                       accumulate);
     JIRF_HIP_CHECK(hipGetLastError());
-    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_window_attention(const float* qkv, long qkv_bs, const float* table, const float* w2, float* out,
+                                long out_bs, int B, int C, int H, int W, int heads, int shift, int coupled, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(qkv && table && w2 && out && B > 0, JIRF_EINVAL, "train_window_attention: bad arguments");
+    const long P = (long)H * W;
+    WinAttnArgs wa{};
+    wa.B = B; wa.C = C; wa.H = H; wa.W = W; wa.heads = heads; wa.shift = shift; wa.coupled = coupled ? 1 : 0;
+    const TV t = tv(const_cast<float*>(qkv), dense(qkv_bs, 3 * C, P));
+    wa.q = tv_chan(t, 0, P); wa.k = tv_chan(t, C, P); wa.v = tv_chan(t, 2 * C, P);
+    wa.out = tv(out, dense(out_bs, C, P));
+    wa.table = table; wa.scale = 1.0f / std::sqrt(32.0f); wa.w_dev = w2;
+    launch_window_attention(wa, static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_window_attention_bwd(const float* qkv, long qkv_bs, const float* table, const float* w2, const float* dout,
+                                    long dout_bs, float* dqkv, long dqkv_bs, float* dtable, float* dw2, int B, int C, int H,
+                                    int W, int heads, int shift, int coupled, int accumulate, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(qkv && table && w2 && dout && dqkv && dtable && dw2 && B > 0 && heads > 0 && C == heads * 32, JIRF_EINVAL,
+                 "window_attention_bwd: bad arguments (head dim 32 only)");
+    JIRF_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8 && (shift == 0 || shift == 4), JIRF_EINVAL,
+                 "window_attention_bwd: %dx%d shift %d", H, W, shift);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long P = (long)H * W;
+    const int n_win = B * (H / 8) * (W / 8);
+    WinBwdArgs a{};
+    a.B = B; a.C = C; a.H = H; a.W = W; a.heads = heads; a.shift = shift; a.coupled = coupled ? 1 : 0;
+    a.chunks = std::max(1, std::min(n_win, (2048 + heads - 1) / heads));
+    a.scale = 1.0f / std::sqrt(32.0f);
+    a.qkv_bs = dense(qkv_bs, 3 * C, P); a.dout_bs = dense(dout_bs, C, P); a.dqkv_bs = dense(dqkv_bs, 3 * C, P);
+    a.q = qkv; a.k = qkv + (long)C * P; a.v = qkv + 2L * C * P; a.dout = dout;
+    a.dq = dqkv; a.dk = dqkv + (long)C * P; a.dv = dqkv + 2L * C * P;
+    a.table = table; a.w2 = w2;
+    a.part_table = static_cast<double*>(train_scratch(SC_PART_A, (size_t)heads * a.chunks * 225 * sizeof(double)));
+    a.part_w = static_cast<double*>(train_scratch(SC_PART_B, (size_t)heads * a.chunks * 2 * sizeof(double)));
+    Scope sc(intern_label("train_win_attn_bwd C%d H%d W%d", C, H, W), 10.0 * 64 * C * (double)P * B, 28.0 * C * (double)P * B, s);
+    hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(a.chunks, heads), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(win_attn_bwd_reduce_kernel, dim3((225 * heads + 255) / 256), dim3(256), 0, s, a.part_table,
+                       a.part_w, w2, heads, a.chunks, dtable, dw2, accumulate);
+    JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });
 }

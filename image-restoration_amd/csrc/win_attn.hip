@@ -221,6 +221,12 @@ __global__ __launch_bounds__(256, 3) void win_attn_mfma_kernel(const WinAttnArgs
     rid_tok = 3 * rh + rw;
   }
 
+  float w_soft = a.w_softmax, w_relu = a.w_relu2;
+  if (a.w_dev) {   // exp(w) / sum(exp(w)) as ast_arch.py:309-311 writes it
+    const float e0 = expf(a.w_dev[0]), e1 = expf(a.w_dev[1]);
+    w_soft = e0 / (e0 + e1);
+    w_relu = e1 / (e0 + e1);
+  }
   // ---- S^T = K Q^T ---------------------------------------------------------------------------------------------
   f32x16 S[2][2];
 #pragma unroll
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_mfma_kernel(const WinAttnArgs
       for (int r = 0; r < 16; ++r) {
         const float sc = S[mt][nt][r];
         const float rl = fmaxf(sc, 0.f);
-        S[mt][nt][r] = (expf(sc - mx) * inv) * a.w_softmax + (rl * rl) * a.w_relu2;
+        S[mt][nt][r] = (expf(sc - mx) * inv) * w_soft + (rl * rl) * w_relu;
       }
   }
 
@@ -312,6 +318,7 @@ void launch_window_attention(const WinAttnArgs& a, hipStream_t s) {
   const double px = (double)a.B * a.H * a.W;
   Scope sc(intern_label("win_attn C%d H%d W%d", a.C, a.H, a.W), 4.0 * 64 * a.C * px, 16.0 * a.C * px, s);
   static const bool valu = std::getenv("JIRF_WINATTN_VALU") != nullptr;
+  JIRF_REQUIRE(!(valu && a.w_dev), JIRF_EINVAL, "window attention: the vector-ALU form takes host mixing weights only");
   if (valu)
     hipLaunchKernelGGL(win_attn_kernel, dim3((n_tasks + 3) / 4), dim3(256), 0, s, a, n_tasks);
   else

@@ -33,7 +33,7 @@ class JirfError(RuntimeError):
 _lib = None
 
 # name -> (restype, argtypes); must list every symbol include/jirf_hip.h declares
-_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_vp, _i, _sz, _l = C.c_void_p, C.c_int, C.c_size_t, C.c_long
 _fp = C.c_void_p  # device or host float*, passed as an address
 SIGNATURES = {
     "jirf_abi_version": (_i, []),
@@ -64,10 +64,20 @@ SIGNATURES = {
     "jirf_train_sumsq": (_i, [_fp, C.c_long, _vp, C.POINTER(C.c_double), _vp]),
     "jirf_train_adam_step": (_i, [_fp, _fp, _fp, _fp, C.c_long, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _i, _i, _vp]),
+    "jirf_train_conv": (_i, [_fp, _l, _fp, _i, _fp, _fp, _l, _fp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_conv_bwd_weight": (_i, [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_train_linear_bwd_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
-    "jirf_train_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
-    "jirf_train_gelu_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
-    "jirf_train_dwconv3x3_bwd_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_layernorm": (_i, [_fp, _l, _fp, _fp, _fp, _l, _i, _i, _i, _i, _vp]),
+    "jirf_train_layernorm_bwd": (_i, [_fp, _l, _fp, _l, _fp, _fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_gelu": (_i, [_fp, _l, _fp, _l, _fp, _l, _i, _l, _i, _vp]),
+    "jirf_train_gelu_bwd": (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _l, _fp, _l, _i, _l, _i, _vp]),
+    "jirf_train_add": (_i, [_fp, _l, _fp, _l, _fp, _l, _i, _l, _vp]),
+    "jirf_train_channel_sum": (_i, [_fp, _l, _fp, _i, _i, _l, _i, _vp]),
+    "jirf_train_dwconv3x3": (_i, [_fp, _l, _fp, _fp, _fp, _l, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_dwconv3x3_bwd_weight": (_i, [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_window_attention": (_i, [_fp, _l, _fp, _fp, _fp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "jirf_train_window_attention_bwd": (_i, [_fp, _l, _fp, _fp, _fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _i, _i,
+                                             _i, _vp]),
     "jirf_op_conv3x3": (_i, [_fp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_dwconv3x3": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

@@ -213,9 +213,15 @@ int jirf_op_psnr_work_doubles(void);
 int jirf_op_psnr_stats(const float* a, const float* b, int C, int H, int W, int crop_border, int quantise, int y_channel,
                        int blue_plane, double* work, void* stream);
 
-/* ---- training step (device side, as far as it is built): the loss, the optimiser update and the
- *      backward of the operators that carry most of AST's parameters.  Raw device pointers, fp32, planar
- *      [B][C][P].  Reference: ImageCleanModel.optimize_parameters, basicsr/models/image_restoration_model.py:235-276. */
+/* ---- training step, device side: the operators of ImageCleanModel.optimize_parameters
+ *      (basicsr/models/image_restoration_model.py:235-276) for AST - forward operators that read the weights from
+ *      DEVICE memory in the reference's layouts (they change every step), their data and weight gradients, the
+ *      loss and the optimiser update.  Raw device pointers, fp32, planar [B][C][P].  An activation argument is
+ *      followed by its batch stride in floats (0 = dense, C * P), so that a channel slice of a wider tensor is a
+ *      pointer offset plus that tensor's stride.  All calls are asynchronous on `stream` unless stated.  The
+ *      operators share one scratch area per device (packed weights, partial sums; grown on demand, kept until the
+ *      process ends): training calls that overlap on one device race.  Every reduction has a fixed order (no
+ *      atomics): a step is reproducible. */
 
 /* Pixel loss of the shipped configurations: "L1Loss" is nn.smooth_l1_loss with mean reduction
  * (basicsr/models/losses/losses.py:12-14,44-52).  *loss_host = loss_weight * mean(l); grad (or NULL) receives
@@ -223,32 +229,83 @@ int jirf_op_psnr_stats(const float* a, const float* b, int C, int H, int W, int 
 int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, long n, float loss_weight,
                          double* loss_host, void* stream);
 /* Sum of squares of a flat buffer in double (the norm of Optimizer.clip_grad_norm,
- * image_restoration_model.py:269-270), to device and / or host memory.  Synchronises `stream`. */
+ * image_restoration_model.py:269-270), to device and / or host memory (host: synchronises `stream`). */
 int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, void* stream);
 /* Gradient clip (max_norm > 0: g *= min(max_norm / (sqrt(*sumsq_dev) + 1e-6), 1)) fused with one Adam step
  * on flat buffers p, g, m, v of n floats; step counts from 1.  torch_form 0: Jittor's update
  * p -= m * lr * sqrt(1 - b1^t) / (1 - b0^t) / (sqrt(v) + eps) (what optimizer_g.step() runs,
- * image_restoration_model.py:215,271); 1: torch.optim.Adam's placement of eps.  Asynchronous on `stream`. */
+ * image_restoration_model.py:215,271); 1: torch.optim.Adam's placement of eps. */
 int jirf_train_adam_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq_dev, float max_norm,
                          float lr, float beta0, float beta1, float eps, int step, int torch_form, void* stream);
-/* Linear / 1x1 convolution y = W x (+ b): dw [M,K] (+)= sum_{b,p} dy[b,:,p] x[b,:,p]^T, db [M] (+)= sum dy
- * (db may be NULL).  nn.Linear of ast_arch.py:100-101,171,456-474.  P % 4 == 0.  The input gradient is the
- * forward kernel on the transposed weights (jirf_op_conv1x1 with w^T). */
+
+/* Convolution / Linear on device weights, as an implicit GEMM (the forward kernels of the inference path;
+ * the weights are packed by a kernel inside the call).  w_kind selects how `w` is read:
+ *   JIRF_W_FWD            w [Cout][Cin][ks][ks] (nn.Conv2d; ks = 1: nn.Linear [Cout][Cin]), geometry ks/stride/pad:
+ *                         y [B,Cout,Hout,Wout] from x [B,Cin,Hin,Win]  (ast_arch.py:100-101,456-474,558-565,630-636)
+ *   JIRF_W_BWD_DATA       the data gradient of a stride-1 convolution whose FORWARD weight is w [Cin][Cout][ks][ks]
+ *                         and forward padding `pad`: x = dY [B,Cin,..], y = dX [B,Cout,..]   (ks = 1: W^T dY)
+ *   JIRF_W_DECONV         nn.ConvTranspose2d(Cin, Cout, 2, stride 2) (ast_arch.py:653-660): w [Cin][Cout][2][2],
+ *                         y [B,Cout,2 Hin,2 Win]; ks/stride/pad are ignored.  Its data gradient is JIRF_W_FWD with
+ *                         the same w read as [Cout' = Cin][Cin' = Cout][2][2], ks 2, stride 2, pad 0.
+ *   JIRF_W_DOWN_BWD_DATA  the data gradient of nn.Conv2d(k 4, stride 2, pad 1) (ast_arch.py:630-636) with forward
+ *                         weight w [Cin][Cout][4][4]: x = dY [B,Cin,Hin,Win], y = dX [B,Cout,2 Hin,2 Win]
+ * epi: 0 y = acc + bias; 1 y = acc + bias + r; 6 y = gelu(acc + bias) (ks = 1); 7 LeakyReLU(0.01) (ks > 1).
+ * bias [Cout] or NULL (device).  r / r_bs only with epi 1. */
+#define JIRF_W_FWD 0
+#define JIRF_W_BWD_DATA 1
+#define JIRF_W_DECONV 2
+#define JIRF_W_DOWN_BWD_DATA 4
+int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const float* bias, const float* r, long r_bs,
+                    float* y, long y_bs, int B, int Cin, int Cout, int Hin, int Win, int ks, int stride, int pad,
+                    int epi, void* stream);
+/* Weight and bias gradient of a convolution / Linear: dw [M][Cin][ks][ks] (+)= sum_{b,oy,ox} dy[b][o][oy][ox]
+ * x[b][c][oy stride - pad + ky][ox stride - pad + kx], db [M] (+)= sum dy (db may be NULL).  Hout * Wout must be
+ * a multiple of 16.  The weight gradient of the transposed convolution is this call with the roles swapped
+ * (dy := its input, x := its output gradient, ks 2, stride 2, pad 0), which yields [Cin][Cout][2][2]. */
+int jirf_train_conv_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, float* db, int B,
+                               int M, int Cin, int Hout, int Wout, int Hin, int Win, int ks, int stride, int pad,
+                               int accumulate, void* stream);
+/* The same for dense [B][M][P] / [B][K][P] operands of a Linear (P % 4 == 0). */
 int jirf_train_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int B, int M, int K, int P,
                                  int accumulate, void* stream);
-/* Per-pixel LayerNorm over channels (ast_arch.py:694,718,743 nn.LayerNorm = kind 1; kind 2 = the BiasFree form of
- * hint_arch.py:98-117): dx [B,C,P], dw [C], db [C] (kind 1) from x, dy and the weight w. */
-int jirf_train_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int B,
-                             int C, int P, int kind, int accumulate, void* stream);
-/* mode 0: dx = dy * gelu'(pre), [B,C,P] (the GELU after linear1, ast_arch.py:384,456).
- * mode 1: the FRFN gate y = gelu(a) * b (ast_arch.py:507-510) with a = pre [B,C,P] and b = x2 the two halves of
- * one [B,2C,P] tensor: dx [B,2C,P] = (dy * b * gelu'(a), dy * gelu(a)). */
-int jirf_train_gelu_bwd(const float* pre, const float* x2, const float* dy, float* dx, int B, int C, int P, int mode,
-                        void* stream);
-/* Depthwise 3x3 (zero pad 1, ast_arch.py:458-466): dw [C,1,3,3] and db [C] (or NULL).  The input gradient is
- * the forward kernel with the taps reversed (jirf_op_dwconv3x3). */
-int jirf_train_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, float* db, int B, int C, int H, int W,
-                                    int accumulate, void* stream);
+/* Per-pixel LayerNorm over channels with device weights (ast_arch.py:694,718,743 nn.LayerNorm = kind 1; kind 2 = the
+ * BiasFree form of hint_arch.py:98-117), and its backward: dx [B,C,P] (+ add, the gradient arriving over the
+ * shortcut around the normalised branch, or NULL), dw [C], db [C] (kind 1) from x, dy and the weight w. */
+int jirf_train_layernorm(const float* x, long x_bs, const float* w, const float* b, float* y, long y_bs, int B, int C,
+                         int P, int kind, void* stream);
+int jirf_train_layernorm_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w, const float* add,
+                             long add_bs, float* dx, long dx_bs, float* dw, float* db, int B, int C, int P, int kind,
+                             int accumulate, void* stream);
+/* Elementwise pieces; one image = n_img contiguous floats.  Forward mode 0: y = gelu(pre) (ast_arch.py:384,456);
+ * mode 1: y = gelu(pre) * x2 (the FRFN gate, ast_arch.py:507-510).  Backward mode 0: dxa = dy * gelu'(pre);
+ * mode 1: dxa = dy * x2 * gelu'(pre), dxb = dy * gelu(pre); mode 2: LeakyReLU(0.01) with pre = the activation's
+ * output: dxa = dy * (pre > 0 ? 1 : 0.01). */
+int jirf_train_gelu(const float* pre, long pre_bs, const float* x2, long x2_bs, float* y, long y_bs, int B, long n_img,
+                    int mode, void* stream);
+int jirf_train_gelu_bwd(const float* pre, long pre_bs, const float* x2, long x2_bs, const float* dy, long dy_bs,
+                        float* dxa, long dxa_bs, float* dxb, long dxb_bs, int B, long n_img, int mode, void* stream);
+/* y = a (+ b, or NULL): concatenation copies and the sums of gradients that meet at a shortcut. */
+int jirf_train_add(const float* a, long a_bs, const float* b, long b_bs, float* y, long y_bs, int B, long n_img,
+                   void* stream);
+/* out [C] (+)= sum_{b,p} x[b][c][p] (the bias gradient of the transposed convolution). */
+int jirf_train_channel_sum(const float* x, long x_bs, float* out, int B, int C, long P, int accumulate, void* stream);
+/* Depthwise 3x3 (zero pad 1, ast_arch.py:458-466) on device weights w [C,1,3,3], bias [C] or NULL; flip != 0 reverses
+ * the taps (the data gradient: x = dY, bias NULL).  Weight / bias gradient: dw [C,1,3,3], db [C] (or NULL). */
+int jirf_train_dwconv3x3(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs, int B, int C,
+                         int H, int W, int flip, void* stream);
+int jirf_train_dwconv3x3_bwd_weight(const float* x, long x_bs, const float* dy, long dy_bs, float* dw, float* db, int B,
+                                    int C, int H, int W, int accumulate, void* stream);
+/* AST's sparse window attention (WindowAttention_sparse.execute ast_arch.py:275-318 with the roll / partition /
+ * mask / reverse of :786-837 as addressing) on qkv [B,3C,H*W] (q | k | v channel blocks, before the q scaling),
+ * 8 x 8 windows, head dim 32, shift 0 or 4; table [225][heads] and w2 [2] (the raw mixing weights `w`) are device
+ * arrays.  coupled 0: the reference's (window, head) pairing of k runs per image (B separate B = 1 calls);
+ * 1: over the whole batch (the literal B > 1 call, what a training batch does).  Backward: dqkv [B,3C,H*W],
+ * dtable [225][heads], dw2 [2]. */
+int jirf_train_window_attention(const float* qkv, long qkv_bs, const float* table, const float* w2, float* out,
+                                long out_bs, int B, int C, int H, int W, int heads, int shift, int coupled, void* stream);
+int jirf_train_window_attention_bwd(const float* qkv, long qkv_bs, const float* table, const float* w2, const float* dout,
+                                    long dout_bs, float* dqkv, long dqkv_bs, float* dtable, float* dw2, int B, int C, int H,
+                                    int W, int heads, int shift, int coupled, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

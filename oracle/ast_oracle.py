@@ -94,6 +94,30 @@ def shift_attn_mask(H: int, W: int, win: int, shift: int) -> torch.Tensor:
     return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
 
 
+def sparse_attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, w: torch.Tensor,
+                          win: int, mask: Optional[torch.Tensor], tap: Tap = None, tap_name: str = "") -> torch.Tensor:
+    """The body of WindowAttention_sparse.execute between the projections (:283-316).  q (already scaled), k, v:
+    [B_, heads, N, d]; returns [B_, N, heads * d]."""
+    B_, heads, N, d = q.shape
+    # k is handed over as [heads, B_, d, N]; bmm_4d flattens it in THAT order while q is flattened
+    # as [B_, heads, ...]: score (b, h) pairs q[b, h] with k[b', h'], h' * B_ + b' = b * heads + h.
+    attn = bmm_4d(q, k.transpose(0, 1).transpose(2, 3))
+    idx = relative_position_index(win).reshape(-1)
+    bias = table[idx].reshape(win * win, win * win, -1).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = attn.reshape(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)
+        attn = attn.reshape(-1, heads, N, N)
+    attn0 = torch.softmax(attn, dim=-1)
+    attn1 = torch.relu(attn) ** 2
+    w_soft = torch.exp(w) / torch.sum(torch.exp(w))
+    attn = attn0 * w_soft[0] + attn1 * w_soft[1]
+    if tap:
+        tap(tap_name, attn.clone())
+    return (attn @ v).transpose(1, 2).reshape(B_, N, heads * d)
+
+
 def window_attention_sparse(p: Params, pre: str, x: torch.Tensor, heads: int, win: int,
                             mask: Optional[torch.Tensor], tap: Tap = None) -> torch.Tensor:
     """WindowAttention_sparse.execute (:275-318) with LinearProjection (:105-117). x: [B_, N, C]."""
@@ -105,25 +129,8 @@ def window_attention_sparse(p: Params, pre: str, x: torch.Tensor, heads: int, wi
     kv = kv.reshape(B_, N, 2, heads, d).permute(2, 0, 3, 1, 4)
     k, v = kv[0], kv[1]
     q = q * (d ** -0.5)
-    # k is handed over as [heads, B_, d, N]; bmm_4d flattens it in THAT order while q is flattened
-    # as [B_, heads, ...]: score (b, h) pairs q[b, h] with k[b', h'], h' * B_ + b' = b * heads + h.
-    attn = bmm_4d(q, k.transpose(0, 1).transpose(2, 3))
-    table = p[pre + ".relative_position_bias_table"]
-    idx = relative_position_index(win).reshape(-1)
-    bias = table[idx].reshape(win * win, win * win, -1).permute(2, 0, 1)
-    attn = attn + bias.unsqueeze(0)
-    if mask is not None:
-        nW = mask.shape[0]
-        attn = attn.reshape(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)
-        attn = attn.reshape(-1, heads, N, N)
-    attn0 = torch.softmax(attn, dim=-1)
-    attn1 = torch.relu(attn) ** 2
-    w = p[pre + ".w"]
-    w_soft = torch.exp(w) / torch.sum(torch.exp(w))
-    attn = attn0 * w_soft[0] + attn1 * w_soft[1]
-    if tap:
-        tap(pre + ".attn", attn.clone())
-    out = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    out = sparse_attention_core(q, k, v, p[pre + ".relative_position_bias_table"], p[pre + ".w"], win, mask, tap,
+                                pre + ".attn")
     return F.linear(out, p[pre + ".proj.weight"], p.get(pre + ".proj.bias"))
 
 

@@ -55,11 +55,12 @@ ASSUMPTIONS = JittorAssumptions()
 
 
 def as_params(state: dict) -> Params:
-    """numpy / torch state dict -> dict of contiguous CPU torch tensors."""
+    """numpy / torch state dict -> dict of contiguous CPU torch tensors.  Tensors that require a gradient are
+    passed through as they are (the training tests differentiate the oracle with torch autograd)."""
     out = {}
     for k, v in state.items():
         t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
-        out[k] = t.detach().cpu().contiguous()
+        out[k] = t if t.requires_grad else t.detach().cpu().contiguous()
     return out
 
 

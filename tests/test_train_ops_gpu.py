@@ -1,9 +1,8 @@
 """Backward / optimiser kernels of the training step against torch autograd over the oracle's operators
 (torch-CPU fp32; the reference's Jittor autograd cannot run here, so this is "parity unpinned" like the
 forward): gradients within 1e-3 relative of autograd's, the loss and the Adam update against a NumPy
-restatement of Jittor's optimizer (jt.optim.Adam.step, Optimizer.clip_grad_norm).  Ends with the backward
-of one whole FRFN token MLP (ast_arch.py:476-513) composed from the kernels, against autograd over
-oracle.ast_oracle.frfn: the operators that hold most of AST's parameters."""
+restatement of Jittor's optimizer (jt.optim.Adam.step, Optimizer.clip_grad_norm).  The whole network's
+backward composed from these operators is in test_train_step_gpu.py."""
 import ctypes as C
 
 import numpy as np
@@ -103,11 +102,21 @@ def test_layernorm_backward(kind, B, Cn, P):
     dx = torch.empty(B, Cn, P, device="cuda")
     dw, db = torch.zeros(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
     xd, dyd, wd = dev(x), dev(dy), dev(w)
-    call("jirf_train_layernorm_bwd", ptr(xd), ptr(dyd), ptr(wd), ptr(dx), ptr(dw), ptr(db), B, Cn, P, kind, 0, stream())
+    call("jirf_train_layernorm_bwd", ptr(xd), 0, ptr(dyd), 0, ptr(wd), None, 0, ptr(dx), 0, ptr(dw), ptr(db), B, Cn, P,
+         kind, 0, stream())
     assert rel_err(dx.cpu().numpy(), xt.grad.numpy()) < REL
     assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < REL
+    # forward with device weights, and the shortcut gradient added on the way out
+    yd = torch.empty(B, Cn, P, device="cuda")
+    bd = dev(b)
+    call("jirf_train_layernorm", ptr(xd), 0, ptr(wd), ptr(bd) if kind == 1 else None, ptr(yd), 0, B, Cn, P, kind, stream())
+    assert rel_err(yd.cpu().numpy(), y.detach().numpy().reshape(B, Cn, P)) < 1e-5
+    call("jirf_train_layernorm_bwd", ptr(xd), 0, ptr(dyd), 0, ptr(wd), ptr(xd), 0, ptr(dx), 0, ptr(dw), ptr(db), B, Cn, P,
+         kind, 1, stream())
+    assert rel_err(dx.cpu().numpy(), xt.grad.numpy() + x) < REL
+    assert rel_err(dw.cpu().numpy(), 2 * wt.grad.numpy()) < REL
     if kind == 1:
-        assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < REL
+        assert rel_err(db.cpu().numpy(), 2 * bt.grad.numpy()) < REL
 
 
 def test_gelu_and_gate_backward():
@@ -117,16 +126,35 @@ def test_gelu_and_gate_backward():
     oc.gelu(pt).backward(torch.from_numpy(dy))
     dx = torch.empty(B, Cn, P, device="cuda")
     pred_, dyd = dev(pre), dev(dy)
-    call("jirf_train_gelu_bwd", ptr(pred_), None, ptr(dyd), ptr(dx), B, Cn, P, 0, stream())
+    call("jirf_train_gelu_bwd", ptr(pred_), 0, None, 0, ptr(dyd), 0, ptr(dx), 0, None, 0, B, Cn * P, 0, stream())
     assert rel_err(dx.cpu().numpy(), pt.grad.numpy()) < 1e-5
+    yf = torch.empty(B, Cn, P, device="cuda")
+    call("jirf_train_gelu", ptr(pred_), 0, None, 0, ptr(yf), 0, B, Cn * P, 0, stream())
+    assert rel_err(yf.cpu().numpy(), oc.gelu(pt).detach().numpy()) < 1e-6
+    # LeakyReLU(0.01) from its output
+    lk = F.leaky_relu(pt.detach(), 0.01).numpy()
+    lkd = dev(lk)
+    call("jirf_train_gelu_bwd", ptr(lkd), 0, None, 0, ptr(dyd), 0, ptr(dx), 0, None, 0, B, Cn * P, 2, stream())
+    assert rel_err(dx.cpu().numpy(), dy * np.where(pre > 0, 1.0, 0.01)) < 1e-6
     both = rnd(B, 2 * Cn, P, scale=1.5, seed=3)
     bt = torch.from_numpy(both).requires_grad_(True)
     a, b2 = bt.chunk(2, dim=1)
     (oc.gelu(a) * b2).backward(torch.from_numpy(dy))
     bd = dev(both)
     dx2 = torch.empty(B, 2 * Cn, P, device="cuda")
-    call("jirf_train_gelu_bwd", ptr(bd), C.c_void_p(bd.data_ptr() + 4 * Cn * P), ptr(dyd), ptr(dx2), B, Cn, P, 1, stream())
+    half = 4 * Cn * P                                   # the two halves of one [B, 2C, P] tensor: batch stride 2 C P
+    call("jirf_train_gelu_bwd", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(dyd), 0, ptr(dx2),
+         2 * Cn * P, C.c_void_p(dx2.data_ptr() + half), 2 * Cn * P, B, Cn * P, 1, stream())
     assert rel_err(dx2.cpu().numpy(), bt.grad.numpy()) < 1e-5
+    call("jirf_train_gelu", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(yf), 0, B, Cn * P, 1,
+         stream())
+    assert rel_err(yf.cpu().numpy(), (oc.gelu(a) * b2).detach().numpy()) < 1e-6
+    # y = a + b on slices, and the channel sum
+    call("jirf_train_add", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(yf), 0, B, Cn * P, stream())
+    assert rel_err(yf.cpu().numpy(), both[:, :Cn] + both[:, Cn:]) < 1e-6
+    cs = torch.zeros(Cn, device="cuda")
+    call("jirf_train_channel_sum", C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(cs), B, Cn, P, 0, stream())
+    assert rel_err(cs.cpu().numpy(), both[:, Cn:].astype(np.float64).sum(axis=(0, 2))) < 1e-5
 
 
 @pytest.mark.parametrize("B,Cn,H,W", [(2, 16, 24, 32), (1, 5, 9, 7)])
@@ -136,92 +164,115 @@ def test_depthwise_backward(B, Cn, H, W):
     F.conv2d(xt, wt, bt, padding=1, groups=Cn).backward(torch.from_numpy(dy))
     dw, db = torch.zeros(Cn, 1, 3, 3, device="cuda"), torch.zeros(Cn, device="cuda")
     xd, dyd = dev(x), dev(dy)
-    call("jirf_train_dwconv3x3_bwd_weight", ptr(xd), ptr(dyd), ptr(dw), ptr(db), B, Cn, H, W, 0, stream())
+    call("jirf_train_dwconv3x3_bwd_weight", ptr(xd), 0, ptr(dyd), 0, ptr(dw), ptr(db), B, Cn, H, W, 0, stream())
     assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < REL
     assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < REL
     dx = torch.empty(B, Cn, H, W, device="cuda")
-    wfd = dev(np.ascontiguousarray(w[:, :, ::-1, ::-1]))
-    call("jirf_op_dwconv3x3", ptr(dyd), ptr(wfd), None, ptr(dx), B, Cn, H, W, 0, stream())
+    wd = dev(w)
+    call("jirf_train_dwconv3x3", ptr(dyd), 0, ptr(wd), None, ptr(dx), 0, B, Cn, H, W, 1, stream())
     assert rel_err(dx.cpu().numpy(), xt.grad.numpy()) < REL
 
 
-def test_frfn_token_mlp_backward_composed_from_the_kernels():
-    """x -> FRFN(x) (ast_arch.py:476-513) with every gradient (input, linear1, dwconv, linear2, partial_conv3
-    excluded: its dense 3x3 weight gradient is not built yet) from the device kernels, against autograd over
-    oracle.ast_oracle.frfn.  Planar layout: tokens [B, L, C] are [B, C, L] here."""
-    B, Cn, S = 2, 32, 16
-    h, P = 4 * Cn, S * S
-    rng = np.random.default_rng(5)
-    p = {"m.linear1.0.weight": rnd(2 * h, Cn, scale=Cn ** -0.5, seed=1), "m.linear1.0.bias": 0.1 * rnd(2 * h, seed=2),
-         "m.dwconv.0.weight": rnd(h, 1, 3, 3, scale=0.3, seed=3), "m.dwconv.0.bias": 0.1 * rnd(h, seed=4),
-         "m.linear2.0.weight": rnd(Cn, h, scale=h ** -0.5, seed=5), "m.linear2.0.bias": 0.1 * rnd(Cn, seed=6),
-         "m.partial_conv3.weight": rnd(Cn // 4, Cn // 4, 3, 3, scale=0.2, seed=7)}
-    x = rng.standard_normal((B, P, Cn)).astype(np.float32)
-    dy = rng.standard_normal((B, P, Cn)).astype(np.float32)
-    pt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in p.items()}
-    xt = torch.from_numpy(x).requires_grad_(True)
-    so.frfn(pt, "m", xt).backward(torch.from_numpy(dy))
 
-    # ---- forward on the CPU up to the stashes a training forward keeps (the forward kernels are tested elsewhere)
-    with torch.no_grad():
-        t = xt.reshape(B, S, S, Cn).permute(0, 3, 1, 2)
-        cat = torch.cat([F.conv2d(t[:, :Cn // 4], pt["m.partial_conv3.weight"], None, padding=1), t[:, Cn // 4:]], 1)
-        cat_p = cat.reshape(B, Cn, P)                                                  # input of linear1, planar
-        pre1 = torch.einsum("ok,bkp->bop", pt["m.linear1.0.weight"], cat_p) + pt["m.linear1.0.bias"][None, :, None]
-        act1 = oc.gelu(pre1)                                                           # [B, 2h, P]: x1 | x2
-        pre_dw = F.conv2d(act1[:, :h].reshape(B, h, S, S), pt["m.dwconv.0.weight"], pt["m.dwconv.0.bias"], padding=1,
-                          groups=h).reshape(B, h, P)
-        gated = oc.gelu(pre_dw) * act1[:, h:]
-    dyp = np.ascontiguousarray(dy.transpose(0, 2, 1))                                   # planar [B, C, P]
-    dyd = dev(dyp)
-    # linear2
-    dw2, db2 = torch.zeros(Cn, h, device="cuda"), torch.zeros(Cn, device="cuda")
-    gated_d = dev(gated.numpy())
-    call("jirf_train_linear_bwd_weight", ptr(dyd), ptr(gated_d), ptr(dw2), ptr(db2), B, Cn, h, P, 0, stream())
-    dgated = torch.empty(B, h, P, device="cuda")
-    call("jirf_op_conv1x1", ptr(dyd), hptr(np.ascontiguousarray(p["m.linear2.0.weight"].T)), None, None, ptr(dgated),
-         B, Cn, h, P, stream())
-    # gate: (d pre_dw, d x2) from (pre_dw | x2)
-    gate_in = dev(np.concatenate([pre_dw.numpy(), act1[:, h:].numpy()], axis=1))
-    dgate = torch.empty(B, 2 * h, P, device="cuda")
-    call("jirf_train_gelu_bwd", ptr(gate_in), C.c_void_p(gate_in.data_ptr() + 4 * h * P), ptr(dgated), ptr(dgate), B, h, P,
-         1, stream())
-    # depthwise: weight / bias gradients and d x1
-    dwdw, dbdw = torch.zeros(h, 1, 3, 3, device="cuda"), torch.zeros(h, device="cuda")
-    x1d = dev(np.ascontiguousarray(act1[:, :h].numpy()))
-    dpre_dw = dgate[:, :h].contiguous()
-    call("jirf_train_dwconv3x3_bwd_weight", ptr(x1d), ptr(dpre_dw), ptr(dwdw), ptr(dbdw), B, h, S, S, 0, stream())
-    dact1 = torch.empty(B, 2 * h, P, device="cuda")
-    dx1 = torch.empty(B, h, P, device="cuda")
-    wfd = dev(np.ascontiguousarray(p["m.dwconv.0.weight"][:, :, ::-1, ::-1]))
-    call("jirf_op_dwconv3x3", ptr(dpre_dw), ptr(wfd), None, ptr(dx1), B, h, S, S, 0, stream())
-    dact1[:, :h] = dx1
-    dact1[:, h:] = dgate[:, h:]
-    # GELU after linear1, then linear1
-    dpre1 = torch.empty(B, 2 * h, P, device="cuda")
-    pre1_d = dev(pre1.numpy())
-    call("jirf_train_gelu_bwd", ptr(pre1_d), None, ptr(dact1), ptr(dpre1), B, 2 * h, P, 0, stream())
-    dw1, db1 = torch.zeros(2 * h, Cn, device="cuda"), torch.zeros(2 * h, device="cuda")
-    cat_d = dev(cat_p.numpy())
-    call("jirf_train_linear_bwd_weight", ptr(dpre1), ptr(cat_d), ptr(dw1), ptr(db1), B, 2 * h, Cn, P, 0, stream())
-    dcat = torch.empty(B, Cn, P, device="cuda")
-    call("jirf_op_conv1x1", ptr(dpre1), hptr(np.ascontiguousarray(p["m.linear1.0.weight"].T)), None, None, ptr(dcat),
-         B, 2 * h, Cn, P, stream())
-    # partial conv: the first C/4 channels go back through the dense 3x3 (transposed, flipped weights), the rest pass
-    wpc = p["m.partial_conv3.weight"]
-    wpc_t = np.ascontiguousarray(wpc.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1])
-    dfirst = torch.empty(B, Cn // 4, P, device="cuda")
-    dcat_first = dcat[:, :Cn // 4].contiguous()
-    call("jirf_op_conv3x3", ptr(dcat_first), hptr(wpc_t), None, None, ptr(dfirst), B, Cn // 4, Cn // 4, S, S, 0, stream())
-    dx = torch.cat([dfirst, dcat[:, Cn // 4:]], dim=1).cpu().numpy().transpose(0, 2, 1)
+W_FWD, W_BWD_DATA, W_DECONV, W_DOWN_BWD = 0, 1, 2, 4
 
-    checks = {"linear2.weight": (dw2, pt["m.linear2.0.weight"].grad), "linear2.bias": (db2, pt["m.linear2.0.bias"].grad),
-              "dwconv.weight": (dwdw, pt["m.dwconv.0.weight"].grad), "dwconv.bias": (dbdw, pt["m.dwconv.0.bias"].grad),
-              "linear1.weight": (dw1, pt["m.linear1.0.weight"].grad), "linear1.bias": (db1, pt["m.linear1.0.bias"].grad)}
-    for name, (got, want) in checks.items():
+
+def _conv(x, w, kind, bias, y, B, Cin, Cout, Hin, Win, ks=1, stride=1, pad=0, epi=0, r=None):
+    call("jirf_train_conv", ptr(x), 0, ptr(w), kind, ptr(bias), ptr(r), 0, ptr(y), 0, B, Cin, Cout, Hin, Win, ks, stride, pad,
+         epi, stream())
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,ks,stride,pad", [(2, 8, 8, 16, 3, 1, 1), (1, 3, 32, 32, 3, 1, 1), (2, 64, 3, 16, 3, 1, 1),
+                                                        (2, 32, 64, 16, 4, 2, 1), (1, 48, 20, 16, 1, 1, 0)])
+def test_convolution_forward_and_both_gradients(B, Cin, Cout, H, ks, stride, pad):
+    """nn.Conv2d on device weights (input / output projections ast_arch.py:558-565,594-600, FRFN's partial 3x3 :470,
+    Downsample :630-636, Linear as ks = 1): forward, data gradient and weight / bias gradient against autograd."""
+    Ho = (H + 2 * pad - ks) // stride + 1
+    x, w, b = rnd(B, Cin, H, H, seed=1), rnd(Cout, Cin, ks, ks, scale=(Cin * ks * ks) ** -0.5, seed=2), rnd(Cout, seed=3)
+    dy = rnd(B, Cout, Ho, Ho, seed=4)
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+    y = F.conv2d(xt, wt, bt, stride=stride, padding=pad)
+    y.backward(torch.from_numpy(dy))
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    yd = torch.empty(B, Cout, Ho, Ho, device="cuda")
+    _conv(xd, wd, W_FWD, bd, yd, B, Cin, Cout, H, H, ks, stride, pad)
+    assert rel_err(yd.cpu().numpy(), y.detach().numpy()) < REL
+    dw, db = torch.full((Cout, Cin, ks, ks), 3.0, device="cuda"), torch.full((Cout,), 3.0, device="cuda")
+    call("jirf_train_conv_bwd_weight", ptr(dyd), 0, ptr(xd), 0, ptr(dw), ptr(db), B, Cout, Cin, Ho, Ho, H, H, ks, stride, pad,
+         0, stream())
+    assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < REL
+    assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < REL
+    dx = torch.empty(B, Cin, H, H, device="cuda")
+    if stride == 1:
+        _conv(dyd, wd, W_BWD_DATA, None, dx, B, Cout, Cin, Ho, Ho, ks, 1, pad)
+    else:
+        _conv(dyd, wd, W_DOWN_BWD, None, dx, B, Cout, Cin, Ho, Ho)
+    assert rel_err(dx.cpu().numpy(), xt.grad.numpy()) < REL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 64, 32, 8), (1, 512, 256, 16)])
+def test_transposed_convolution_forward_and_both_gradients(B, Cin, Cout, H):
+    """nn.ConvTranspose2d(k 2, stride 2) (Upsample ast_arch.py:653-660)."""
+    x, w, b = rnd(B, Cin, H, H, seed=1), rnd(Cin, Cout, 2, 2, scale=Cin ** -0.5, seed=2), rnd(Cout, seed=3)
+    dy = rnd(B, Cout, 2 * H, 2 * H, seed=4)
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+    y = F.conv_transpose2d(xt, wt, bt, stride=2)
+    y.backward(torch.from_numpy(dy))
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    yd = torch.empty(B, Cout, 2 * H, 2 * H, device="cuda")
+    _conv(xd, wd, W_DECONV, bd, yd, B, Cin, Cout, H, H)
+    assert rel_err(yd.cpu().numpy(), y.detach().numpy()) < REL
+    dx = torch.empty(B, Cin, H, H, device="cuda")
+    _conv(dyd, wd, W_FWD, None, dx, B, Cout, Cin, 2 * H, 2 * H, 2, 2, 0)
+    assert rel_err(dx.cpu().numpy(), xt.grad.numpy()) < REL
+    dw, db = torch.zeros(Cin, Cout, 2, 2, device="cuda"), torch.zeros(Cout, device="cuda")
+    call("jirf_train_conv_bwd_weight", ptr(xd), 0, ptr(dyd), 0, ptr(dw), None, B, Cin, Cout, H, H, 2 * H, 2 * H, 2, 2, 0, 0,
+         stream())
+    call("jirf_train_channel_sum", ptr(dyd), 0, ptr(db), B, Cout, 4 * H * H, 0, stream())
+    assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < REL
+    assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < REL
+
+
+@pytest.mark.parametrize("coupled", [0, 1])
+@pytest.mark.parametrize("B,heads,S,shift", [(2, 2, 16, 0), (2, 4, 16, 4), (1, 16, 8, 4), (3, 1, 24, 4)])
+def test_window_attention_forward_and_backward(B, heads, S, shift, coupled):
+    """WindowAttention_sparse (ast_arch.py:275-318) inside the shift / partition / reverse of TransformerBlock
+    (:786-837), from the fused q | k | v tensor: output and the gradients of qkv, the bias table and the mixing
+    weights against autograd over the oracle.  coupled = 0 is B separate calls, 1 the literal batched call."""
+    Cn, P = 32 * heads, S * S
+    qkv = rnd(B, 3 * Cn, P, scale=0.7, seed=1)
+    table, w2 = rnd(225, heads, scale=0.3, seed=2), np.array([0.3, -0.2], np.float32)
+    dout = rnd(B, Cn, P, seed=3)
+    qt, tt, wt = (torch.from_numpy(a).requires_grad_(True) for a in (qkv, table, w2))
+
+    def oracle(q3):                         # q3: [b, 3C, P] planar -> [b, C, P]
+        b = q3.shape[0]
+        tok = q3.reshape(b, 3 * Cn, S, S).permute(0, 2, 3, 1)                       # [b, S, S, 3C]
+        if shift:
+            tok = torch.roll(tok, shifts=(-shift, -shift), dims=(1, 2))
+        wins = so.window_partition(tok, 8).reshape(-1, 64, 3 * Cn)
+        B_ = wins.shape[0]
+        q = wins[..., :Cn].reshape(B_, 64, heads, 32).permute(0, 2, 1, 3) * 32 ** -0.5
+        k = wins[..., Cn:2 * Cn].reshape(B_, 64, heads, 32).permute(0, 2, 1, 3)
+        v = wins[..., 2 * Cn:].reshape(B_, 64, heads, 32).permute(0, 2, 1, 3)
+        mask = so.shift_attn_mask(S, S, 8, shift) if shift else None
+        o = so.sparse_attention_core(q, k, v, tt, wt, 8, mask).reshape(B_, 8, 8, Cn)
+        o = so.window_reverse(o, 8, S, S)
+        if shift:
+            o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+        return o.permute(0, 3, 1, 2).reshape(b, Cn, P)
+
+    out = oracle(qt) if coupled else torch.cat([oracle(qt[i:i + 1]) for i in range(B)])
+    out.backward(torch.from_numpy(dout))
+    qd, td, wd, dod = dev(qkv), dev(table), dev(w2), dev(dout)
+    od = torch.empty(B, Cn, P, device="cuda")
+    call("jirf_train_window_attention", ptr(qd), 0, ptr(td), ptr(wd), ptr(od), 0, B, Cn, S, S, heads, shift, coupled, stream())
+    assert rel_err(od.cpu().numpy(), out.detach().numpy()) < REL
+    dq = torch.full((B, 3 * Cn, P), 7.0, device="cuda")
+    dt, dw = torch.zeros(225, heads, device="cuda"), torch.zeros(2, device="cuda")
+    call("jirf_train_window_attention_bwd", ptr(qd), 0, ptr(td), ptr(wd), ptr(dod), 0, ptr(dq), 0, ptr(dt), ptr(dw), B, Cn, S, S,
+         heads, shift, coupled, 0, stream())
+    for name, got, want in (("qkv", dq, qt.grad), ("table", dt, tt.grad), ("w", dw, wt.grad)):
         e = rel_err(got.cpu().numpy(), want.numpy())
-        print(f"[frfn backward] {name}: relative error {e:.2e}")
+        print(f"[window attention backward B={B} heads={heads} S={S} shift={shift} coupled={coupled}] {name}: {e:.2e}")
         assert e < REL, name
-    e = rel_err(dx, xt.grad.numpy())
-    print(f"[frfn backward] input: relative error {e:.2e}")
-    assert e < REL

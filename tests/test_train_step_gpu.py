@@ -1,0 +1,138 @@
+"""The AST optimisation step (reference basicsr/models/image_restoration_model.py:235-276) on the GPU against
+torch autograd over the oracle's forward (oracle/ast_oracle.py, torch-CPU fp32; "parity unpinned": Jittor's
+own autograd cannot run here) and a NumPy restatement of Jittor's clip_grad_norm + Adam:
+
+ * every parameter's gradient of the smooth-L1 loss, full depth-2 AST on a batch of two 128 x 128 crops
+   (the literal batched call: the window / head pairing of K runs over the whole batch), within 1e-3 of
+   autograd's, and the fraction of parameters covered (all of them);
+ * the weights after iteration 1 (no clip) and iteration 2 (clip 0.01) against the oracle's;
+ * the training forward equals the inference forward of the same weights.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ast_oracle as so
+from oracle.weights import make_ast_state
+from tests.gpu_util import max_abs
+
+pytestmark = pytest.mark.gpu
+REL = 1e-3
+
+
+def _cfg():
+    cfg = so.default_config()
+    cfg["depths"] = [1, 1, 1, 1, 2, 1, 1, 1, 2]      # shifted blocks at the bottleneck and at full resolution
+    return cfg
+
+
+def _state(cfg, seed):
+    """Synthetic AST weights, trainable tensors only (the index buffer of the bias table is not a parameter)."""
+    return {k: np.asarray(v, np.float32) for k, v in make_ast_state(cfg, seed=seed, gain=0.5).items()
+            if not k.endswith("relative_position_index")}
+
+
+def _data(B, S, seed):
+    rng = np.random.default_rng(seed)
+    gt = rng.random((B, 3, S, S), dtype=np.float32)
+    lq = np.clip(gt + 0.1 * rng.standard_normal((B, 3, S, S)).astype(np.float32), 0, 1).astype(np.float32)
+    return lq, gt
+
+
+def _oracle_grads(sd, lq, gt, cfg):
+    params = {k: torch.from_numpy(np.ascontiguousarray(v)).requires_grad_(True) for k, v in sd.items()}
+    pred = so.ast_forward(params, torch.from_numpy(lq), cfg)
+    loss = F.smooth_l1_loss(pred, torch.from_numpy(gt), reduction="none").mean()      # losses.py:12-14
+    loss.backward()
+    return float(loss.detach()), pred.detach().numpy(), {k: v.grad.numpy() for k, v in params.items()}
+
+
+def _jittor_adam(p, g, m, v, step, lr=2e-4, b0=0.9, b1=0.999, eps=1e-8, clip=None):
+    """jt.optim.Optimizer.clip_grad_norm(max_norm, 2) over all parameters, then jt.optim.Adam.step."""
+    if clip is not None:
+        total = np.sqrt(sum(float(np.sum(x.astype(np.float64) ** 2)) for x in g.values()))
+        coef = min(clip / (total + 1e-6), 1.0)
+        g = {k: x * np.float32(coef) for k, x in g.items()}
+    out = {}
+    for k in p:
+        m[k] = b0 * m[k] + (1 - b0) * g[k]
+        v[k] = b1 * v[k] + (1 - b1) * g[k] * g[k]
+        out[k] = p[k] - m[k] * (lr * np.sqrt(1 - b1 ** step) / (1 - b0 ** step)) / (np.sqrt(v[k]) + eps)
+    return out
+
+
+def test_gradients_and_two_steps_against_the_oracle():
+    from jirf_hip.train import AstTrainStep
+    cfg = _cfg()
+    sd = _state(cfg, 11)
+    lq, gt = _data(2, 128, 3)
+    loss_ref, pred_ref, g_ref = _oracle_grads(sd, lq, gt, cfg)
+
+    tr = AstTrainStep(cfg, sd, lr=2e-4, coupled=True)
+    loss, pred = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt))
+    assert max_abs(pred.cpu().numpy(), pred_ref) < 1e-3
+    assert abs(loss - loss_ref) < 1e-5 * abs(loss_ref)
+    g = tr.grad_dict()
+    worst, covered = ("", 0.0), 0
+    for k, want in g_ref.items():
+        scale = max(float(np.abs(want).max()), 1e-12)
+        e = float(np.abs(g[k] - want).max()) / scale
+        if e > worst[1]:
+            worst = (k, e)
+        covered += want.size if e < REL else 0
+        assert e < REL, f"{k}: relative error {e:.2e}"
+    total = sum(v.size for v in g_ref.values())
+    print(f"[AST training step] loss {loss:.6f} (oracle {loss_ref:.6f}); gradients verified for {covered}/{total} "
+          f"parameters ({len(g_ref)} tensors); worst {worst[0]} {worst[1]:.2e}")
+    assert covered == total == tr.num_parameters()
+
+    # ---- iteration 1 (clip only from the second iteration on, image_restoration_model.py:269), then iteration 2
+    m = {k: np.zeros_like(v) for k, v in sd.items()}
+    v = {k: np.zeros_like(x) for k, x in sd.items()}
+    p1_ref = _jittor_adam(sd, g_ref, m, v, 1)
+    tr.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), current_iter=1)
+    p1 = tr.state_dict()
+    for k in sd:
+        # the first Adam step moves every weight by ~lr whatever the gradient's size (m / sqrt(v) = +-1), so the
+        # comparison is of the step direction: a wrong sign would show as 2 lr
+        assert np.abs(p1[k] - p1_ref[k]).max() < 0.05 * 2e-4 + 1e-6 * np.abs(sd[k]).max(), k
+    lq2, gt2 = _data(2, 128, 4)
+    p1f = {k: np.asarray(x, np.float32) for k, x in p1_ref.items()}
+    _, _, g2_ref = _oracle_grads(p1f, lq2, gt2, cfg)
+    p2_ref = _jittor_adam(p1f, g2_ref, m, v, 2, clip=0.01)
+    loss2 = tr.optimize_parameters(torch.from_numpy(lq2), torch.from_numpy(gt2), current_iter=2)
+    p2 = tr.state_dict()
+    err = max(float(np.abs(p2[k] - p2_ref[k]).max()) for k in sd)
+    moved = max(float(np.abs(p2_ref[k] - sd[k]).max()) for k in sd)
+    print(f"[AST training step] after two iterations: max |w - w_oracle| = {err:.2e} (weights moved by up to {moved:.2e}); "
+          f"loss {loss2:.6f}")
+    assert err < 0.1 * moved
+
+
+def test_training_forward_equals_the_inference_forward():
+    from basicsr.models.archs import define_network
+    from jirf_hip.train import AstTrainStep
+    cfg = so.default_config()
+    sd = _state(cfg, 5)
+    lq, gt = _data(2, 128, 7)
+    net = define_network(dict(cfg, type="AST"))
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    for coupled, mode in ((False, "per_image"), (True, "coupled")):
+        tr = AstTrainStep(cfg, sd, coupled=coupled)
+        _, pred = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt), backward=False)
+        net.batch_mode = mode
+        y = net(torch.from_numpy(lq).cuda())
+        assert max_abs(pred.cpu().numpy(), y.cpu().numpy()) < 2e-5, mode
+
+
+def test_a_few_steps_reduce_the_loss():
+    from jirf_hip.train import AstTrainStep
+    cfg = _cfg()
+    sd = _state(cfg, 2)
+    lq, gt = _data(1, 128, 9)
+    tr = AstTrainStep(cfg, sd, lr=1e-3, use_grad_clip=False)
+    losses = [tr.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt)) for _ in range(6)]
+    print("[AST training step] losses on one fixed batch:", " ".join(f"{x:.5f}" for x in losses))
+    assert losses[-1] < losses[0]
