@@ -97,7 +97,8 @@ def _dominant(detail):
     name, a = max(detail.items(), key=lambda kv: kv[1]["ms"])
     family = name.split(" ")[0]
     per_launch_s = a["ms"] / 1e3 / a["launches"]
-    if family.startswith("gemm") or family == "hint_chan_stats" or family.startswith("win_attn"):
+    if family.startswith("gemm") or family == "hint_chan_stats" or family.startswith("win_attn") or \
+            family in ("train_dw", "train_win_attn_bwd"):
         ach = a["flops"] / a["launches"] / per_launch_s / 1e12
         return name, {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                       "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
@@ -167,6 +168,120 @@ def run_extra_config(nets, arch, B, Hh, Ww, steps, warmup=2, crop=0, overlap=0, 
     return rec
 
 
+def train_step_bench(args, rank, local_rank, world, use_dist):
+    """One AST optimisation step per "step" (reference basicsr/models/image_restoration_model.py:235-276: forward,
+    smooth-L1, backward, gradient mean over the ranks, clip 0.01, Adam) on a batch of --train-batch crops per GPU
+    (Enhancement/Options/AST_LOL_v2_synthetic.yml: mini-batch 2 at the 256-pixel stage of the progressive schedule).
+    Every rank holds a full replica and its own crops; the only exchange is the all-reduce of the flat gradient
+    buffer (RCCL), plus the scalar mean of the logged loss."""
+    import torch.distributed as dist
+    from jirf_hip.synthetic import default_config, make_state, synthetic_images
+    from jirf_hip.train import AstTrainStep
+    cfg = default_config("AST")
+    sd = make_state("AST", cfg, seed=1)
+    B, S = args.train_batch, args.size
+    tr = AstTrainStep(cfg, sd, device=local_rank, lr=2e-4, use_grad_clip=True, coupled=True)
+    tr.broadcast_parameters()
+    gt = torch.from_numpy(synthetic_images(B, S, S, seed=500 + rank, sigma=0)).cuda()
+    lq = torch.from_numpy(synthetic_images(B, S, S, seed=500 + rank, sigma=25)).cuda()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(tr.optimize_parameters(lq, gt))
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(tr.optimize_parameters(lq, gt))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(np.isfinite(losses)), "non-finite loss"
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {
+        "metric": f"trained megapixels/sec (node), AST optimisation step, {S}x{S} crops",
+        "value": round(world * B * S * S / 1e6 / (ms_per_step / 1e3), 3), "unit": "MP/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "images_per_s": round(world * B / (ms_per_step / 1e3), 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (uniform [0,1) RGB targets, inputs = targets + N(0,(25/255)^2); seeded random weights in the "
+                "reference key layout, broadcast from rank 0)",
+        "config": {"workload": f"AST (reference default constructor, token_mlp frfn, {tr.num_parameters()} parameters) "
+                               f"optimisation step on {B} {S}x{S} crops per GPU: forward, smooth-L1, backward, gradient "
+                               "all-reduce (mean), clip 0.01, Adam; fp32; stochastic depth off",
+                   "batch_per_gpu": B, "height": S, "width": S,
+                   "sharding": "one replica per rank, one all-reduce of the flat gradient buffer per step",
+                   "gradient_floats": tr.n_flat},
+        "loss_first": round(losses[0], 6), "loss_last": round(losses[-1], 6),
+    }
+    if use_dist and world > 1:
+        # the exchange on its own: the same all-reduce, timed outside the step
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            tr.average_gradients()
+        sync_all()
+        out["allreduce_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+    if rank == 0 and world == 1 and not args.no_roofline:
+        tr.kernel_timing(True)
+        acc, detail = {}, {}
+        for _ in range(max(1, min(args.steps, 3))):
+            tr.optimize_parameters(lq, gt)
+            torch.cuda.synchronize()
+            for k in tr.kernel_times():
+                for table, key in ((acc, k["name"].split(" ")[0]), (detail, k["name"])):
+                    a = table.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                    for f in ("ms", "flops", "bytes", "launches"):
+                        a[f] += k[f]
+        tr.kernel_timing(False)
+        n_rep = max(1, min(args.steps, 3))
+        if args.detail:
+            with open(args.detail, "w") as fh:
+                for k, v in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
+                    fh.write(f"{v['ms'] / n_rep:9.3f} ms/step  {v['launches'] // n_rep:4d} launches  "
+                             f"{v['flops'] / (v['ms'] / 1e3) / 1e12 if v['ms'] else 0:7.2f} TFLOP/s  "
+                             f"{v['bytes'] / (v['ms'] / 1e3) / 1e9 if v['ms'] else 0:8.1f} GB/s  {k}\n")
+        tot_ms = sum(a["ms"] for a in acc.values())
+        name, roof = _dominant(detail)
+        a = detail[name]
+        roof.update({"traffic": None, "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                     "algorithmic_flops_per_launch": a["flops"] / a["launches"],
+                     "launches_per_step": a["launches"] // n_rep,
+                     "avg_launch_us": round(a["ms"] / a["launches"] * 1e3, 2),
+                     "share_of_device_time": round(a["ms"] / tot_ms, 4)})
+        out["roofline"] = roof
+        out["device_ms_per_step"] = round(tot_ms / n_rep, 3)
+        out["kernels"] = {k: {"ms_per_step": round(v["ms"] / n_rep, 3), "launches_per_step": v["launches"] // n_rep,
+                              "tflops": round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) if v["ms"] > 0 else 0,
+                              "gbs": round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) if v["ms"] > 0 else 0}
+                          for k, v in sorted(acc.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample: forward + backward of ONE crop of the batch through the oracle with torch autograd on the
+        # host cores (the only place the benchmark touches oracle/)
+        import torch.nn.functional as F
+        from oracle.ast_oracle import ast_forward
+        cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        torch.set_num_threads(cores)
+        params = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).requires_grad_(True)
+                  for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+        t0 = time.perf_counter()
+        pred = ast_forward(params, lq[:1].cpu(), cfg)
+        F.smooth_l1_loss(pred, gt[:1].cpu(), reduction="none").mean().backward()
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(S * S / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
+                               "sample": f"forward + backward of 1 crop {S}x{S} through the oracle/ restatement of AST with "
+                                         f"torch autograd (torch-CPU fp32, {cores} threads), {dt:.1f} s; no optimiser update"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +302,9 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the `configs` array (the other shapes of the BASELINE metric, N = 1 only)")
     ap.add_argument("--detail", default=None, help="write the per-shape kernel table to this file")
+    ap.add_argument("--train-step", action="store_true",
+                    help="time the AST data-parallel optimisation step instead of the inference forward")
+    ap.add_argument("--train-batch", type=int, default=2, help="crops per GPU per optimisation step (--train-step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,6 +321,15 @@ def main():
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.train_step:
+        out = train_step_bench(args, rank, local_rank, world, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
 
     from jirf_hip.synthetic import default_config, make_state, synthetic_images
     from basicsr.models.archs import define_network

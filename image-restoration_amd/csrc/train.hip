@@ -136,16 +136,17 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   double dbacc = 0.0;   // lane: row m0 + lane, over this wave's chunks
   const int lr = lane / NT_LPR, lc = (lane % NT_LPR) * 4;   // loader: NT_RPI rows x NT_LPR float4 per instruction
-  for (long c = c_lo + wave; c < c_hi; c += 4) {
+  // the chunk's global loads: issued one chunk ahead, so that they are in flight during the MFMA phase
+  float4 va[NT_U], vb[NT_U];
+  auto fetch = [&](long c) {
     const int b = (int)(c / chunks_img);
     const int p0 = (int)(c - (long)b * chunks_img) * NT_PX;
     const float* __restrict__ dyb = dy + (long)b * dy_bs;
     const float* __restrict__ xb = x + (long)b * x_bs;
-    float4 va[NT_U], vb[NT_U];
 #pragma unroll
     for (int u = 0; u < NT_U; ++u) {
       const int row = lr + NT_RPI * u;
-      const int pa = min(p0 + lc, P - 4);   // clamped address; the tail is zeroed below
+      const int pa = min(p0 + lc, P - 4);   // clamped address; the tail is zeroed when the chunk is staged
       va[u] = *reinterpret_cast<const float4*>(dyb + (long)min(m0 + row, M - 1) * P + pa);
       if constexpr (!CONV) {
         vb[u] = *reinterpret_cast<const float4*>(xb + (long)min(k0 + row, K - 1) * P + pa);
@@ -165,6 +166,10 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restri
         vb[u] = make_float4(g4[0], g4[1], g4[2], g4[3]);
       }
     }
+  };
+  if (c_lo + wave < c_hi) fetch(c_lo + wave);
+  for (long c = c_lo + wave; c < c_hi; c += 4) {
+    const int p0 = (int)(c - (c / chunks_img) * chunks_img) * NT_PX;
 #pragma unroll
     for (int u = 0; u < NT_U; ++u) {
       const int row = lr + NT_RPI * u;
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restri
         Bm[row * NT_LD + lc + j] = (okb && pin) ? b4[j] : 0.f;
       }
     }
+    if (c + 4 < c_hi) fetch(c + 4);
     // (the wave's own region: its writes are visible to its reads after the LDS counter wait)
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
     if (blockIdx.y == 0) {
@@ -248,62 +254,121 @@ __global__ __launch_bounds__(256) void reduce_parts_d_kernel(const double* __res
   out[e] = accumulate ? out[e] + (float)t : (float)t;
 }
 
+// out[c] (+)= sum over slots of part[slot][c], one workgroup per column: thread t adds slots t, t + 256, ... and
+// the 256 sums meet in a tree of fixed shape, so the result does not depend on timing.
+__global__ __launch_bounds__(256) void reduce_cols_d_kernel(const double* __restrict__ part, int n, int slots,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double t = 0.0;
+  for (int s = threadIdx.x; s < slots; s += 256) t += part[(long)s * n + c];
+  t = block_sum_d(t, red);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)t : (float)t;
+}
+
 // ---- LayerNorm over channels, backward ----------------------------------------------------------------
 // n = (x - mu) rs (WithBias) or x rs (BiasFree, hint/astv2; AST's nn.LayerNorm is the WithBias form);
 // y = n w + b.  With g = dy w per channel:
 //   WithBias:  dx = rs (g - mean_c(g) - nhat mean_c(g nhat)),  nhat = (x - mu) rs
 //   BiasFree:  dx = rs g - (x - mu) rs^3 mean_c(g x)          (the variance still centres x)
-// A thread owns one pixel and loops over the channels twice (loads along pixels are coalesced).
-// dw / db partial sums per workgroup: part_w / part_b [gridDim.x * B... ][C], reduced by reduce_parts_d_kernel.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long x_bs,
-                                                            const float* __restrict__ dy, long dy_bs,
-                                                            const float* __restrict__ w,
-                                                            const float* __restrict__ add, long add_bs,
-                                                            float* __restrict__ dx, long dx_bs,
-                                                            double* __restrict__ part_w, double* __restrict__ part_b,
-                                                            int C, int P, int with_bias) {
-  extern __shared__ double ln_red[];   // [256]
-  const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
+// A workgroup of NW waves owns 64 pixels (lane = pixel); wave w takes the channels w, w + NW, ... in both passes,
+// four of them per loop trip so that eight loads per lane are in flight.  Pass 1 sums x, x^2, g and g x about the
+// pixel's first channel (shifted data keeps the one-pass variance as accurate as the two-pass form); the waves'
+// sums meet in LDS and are added in wave order.  Pass 2 writes dx and reduces the parameter gradients
+// dw[c] = sum dy n, db[c] = sum dy over the 64 pixels with cross-lane shuffles: one partial per (workgroup,
+// channel), added up in workgroup order by reduce_parts_d_kernel.  NW = 16 where the plane is small (few
+// workgroups, many channels each), 4 otherwise.
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __restrict__ x, long x_bs,
+                                                                const float* __restrict__ dy, long dy_bs,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ add, long add_bs,
+                                                                float* __restrict__ dx, long dx_bs,
+                                                                double* __restrict__ part_w,
+                                                                double* __restrict__ part_b, int C, int P,
+                                                                int with_bias) {
+  __shared__ float st[NW][4][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
   const bool on = p < P;
-  const float* __restrict__ xb = x + (long)b * x_bs + (on ? p : 0);
-  const float* __restrict__ gb = dy + (long)b * dy_bs + (on ? p : 0);
-  float sum = 0.f;
-  for (int c = 0; c < C; ++c) sum += xb[(long)c * P];
-  const float mu = sum / (float)C;
-  float var = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float d = xb[(long)c * P] - mu;
-    var = fmaf(d, d, var);
+  const long off = on ? p : 0;
+  const float* __restrict__ xb = x + (long)b * x_bs + off;
+  const float* __restrict__ gb = dy + (long)b * dy_bs + off;
+  const float piv = xb[0];
+  float sx = 0.f, sxx = 0.f, sg = 0.f, sgx = 0.f;
+  for (int c0 = wave; c0 < C; c0 += 4 * NW) {
+    float xv[4], gv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = min(c0 + j * NW, C - 1);
+      xv[j] = xb[(long)c * P];
+      gv[j] = gb[(long)c * P] * w[c];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j * NW < C) {
+        const float d = xv[j] - piv;
+        sx += d;
+        sxx = fmaf(d, d, sxx);
+        sg += gv[j];
+        sgx = fmaf(gv[j], d, sgx);
+      }
   }
-  const float rs = 1.0f / sqrtf(var / (float)C + 1e-5f);
-  float s1 = 0.f, s2 = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float g = gb[(long)c * P] * w[c];
-    const float xv = xb[(long)c * P];
-    s1 += g;
-    s2 += with_bias ? g * (xv - mu) * rs : g * xv;
+  st[wave][0][lane] = sx;
+  st[wave][1][lane] = sxx;
+  st[wave][2][lane] = sg;
+  st[wave][3][lane] = sgx;
+  __syncthreads();
+  sx = sxx = sg = sgx = 0.f;
+#pragma unroll
+  for (int v = 0; v < NW; ++v) {
+    sx += st[v][0][lane];
+    sxx += st[v][1][lane];
+    sg += st[v][2][lane];
+    sgx += st[v][3][lane];
   }
-  s1 /= (float)C;
-  s2 /= (float)C;
-  float* __restrict__ dxb = dx + (long)b * dx_bs + (on ? p : 0);
-  const float* __restrict__ adb = add ? add + (long)b * add_bs + (on ? p : 0) : nullptr;   // + gradient of the shortcut
+  const float invC = 1.0f / (float)C;
+  const float md = sx * invC;                       // mean of (x - pivot)
+  const float var = fmaxf(sxx * invC - md * md, 0.f);
+  const float mu = piv + md;
+  const float rs = 1.0f / sqrtf(var + 1e-5f);
+  const float s1 = sg * invC;
+  // WithBias: mean_c(g nhat) = rs mean_c(g (x - mu));  BiasFree: mean_c(g x)
+  const float s2 = with_bias ? rs * (sgx - md * sg) * invC : (sgx + piv * sg) * invC;
+  float* __restrict__ dxb = dx + (long)b * dx_bs + off;
+  const float* __restrict__ adb = add ? add + (long)b * add_bs + off : nullptr;   // + gradient of the shortcut
   const long slot = ((long)blockIdx.y * gridDim.x + blockIdx.x) * C;
-  for (int c = 0; c < C; ++c) {
-    const float xv = xb[(long)c * P], dyv = gb[(long)c * P];
-    const float g = dyv * w[c];
-    const float nh = (xv - mu) * rs;
-    float o;
-    if (with_bias) o = rs * (g - s1 - nh * s2);
-    else o = rs * g - (xv - mu) * rs * rs * rs * s2;
-    if (adb) o += adb[(long)c * P];
-    if (on) dxb[(long)c * P] = o;
-    // parameter gradients: dw[c] = sum dy n, db[c] = sum dy  (n = nhat or x rs)
-    const double tw = block_sum_d(on ? (double)dyv * (with_bias ? nh : xv * rs) : 0.0, ln_red);
-    const double tb = block_sum_d(on ? (double)dyv : 0.0, ln_red);
-    if (threadIdx.x == 0) {
-      part_w[slot + c] = tw;
-      part_b[slot + c] = tb;
+  for (int c0 = wave; c0 < C; c0 += 4 * NW) {
+    float xv[4], dv[4], av[4], wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = min(c0 + j * NW, C - 1);
+      xv[j] = xb[(long)c * P];
+      dv[j] = gb[(long)c * P];
+      av[j] = adb ? adb[(long)c * P] : 0.f;
+      wv[j] = w[c];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j * NW;
+      if (c >= C) break;               // uniform over the wave
+      const float g = dv[j] * wv[j];
+      const float nh = (xv[j] - mu) * rs;
+      float o;
+      if (with_bias) o = rs * (g - s1 - nh * s2);
+      else o = rs * g - (xv[j] - mu) * rs * rs * rs * s2;
+      if (on) dxb[(long)c * P] = o + av[j];
+      const float tw = wave_sum_f(on ? dv[j] * (with_bias ? nh : xv[j] * rs) : 0.f);
+      const float tb = wave_sum_f(on ? dv[j] : 0.f);
+      if (lane == 0) {
+        part_w[slot + c] = (double)tw;
+        part_b[slot + c] = (double)tb;
+      }
     }
   }
 }
@@ -376,17 +441,20 @@ __global__ void flip9_kernel(const float* __restrict__ w, float* __restrict__ ou
 
 // ---- depthwise 3x3, weight and bias gradients -------------------------------------------------------------
 // dw[c][ky][kx] = sum_{b,y,x} dy[b][c][y][x] * x[b][c][y + ky - 1][x + kx - 1] (zero padded), db[c] = sum dy.
-// One workgroup per (channel, image): nine + one sums in double; part [B][C][10], reduced in image order.
+// One workgroup per (channel, image, slab of the plane): nine + one sums in double; part [B * slabs][C][10],
+// reduced in (image, slab) order.
 __global__ __launch_bounds__(256) void dwconv_dw_kernel(const float* __restrict__ x, long x_bs,
                                                         const float* __restrict__ dy, long dy_bs,
-                                                        double* __restrict__ part, int C, int H, int W) {
+                                                        double* __restrict__ part, int C, int H, int W, int slabs) {
   __shared__ double red[256];
-  const int c = blockIdx.x, b = blockIdx.y;
+  const int c = blockIdx.x, b = blockIdx.y / slabs, slab = blockIdx.y - b * slabs;
   const float* __restrict__ xp = x + (long)b * x_bs + (long)c * H * W;
   const float* __restrict__ gp = dy + (long)b * dy_bs + (long)c * H * W;
   double acc[10];
   for (int t = 0; t < 10; ++t) acc[t] = 0.0;
-  for (int i = threadIdx.x; i < H * W; i += 256) {
+  const int per = (H * W + slabs - 1) / slabs;
+  const int hi = min(H * W, (slab + 1) * per);
+  for (int i = slab * per + threadIdx.x; i < hi; i += 256) {
     const int yy = i / W, xx = i - yy * W;
     const float g = gp[i];
     acc[9] += g;
@@ -400,7 +468,7 @@ __global__ __launch_bounds__(256) void dwconv_dw_kernel(const float* __restrict_
   }
   for (int t = 0; t < 10; ++t) {
     const double v = block_sum_d(acc[t], red);
-    if (threadIdx.x == 0) part[((long)b * C + c) * 10 + t] = v;
+    if (threadIdx.x == 0) part[((long)blockIdx.y * C + c) * 10 + t] = v;
   }
 }
 __global__ __launch_bounds__(256) void dwconv_dw_reduce_kernel(const double* __restrict__ part, int B, int C,
@@ -461,7 +529,7 @@ __global__ void expand_bias4_kernel(const float* __restrict__ b, float* __restri
 // and dk goes back there: the pairing is a bijection, so every gradient element has one writer.  The table
 // gradient is gathered from the transposed dS tile (lane = table entry: no two lanes ever add to one address),
 // kept with the mixing-weight sums per workgroup and added up afterwards in a fixed order.
-constexpr int WB_LD = 33, WB_TLD = 65;
+constexpr int WB_LD = 36, WB_TLD = 65;   // operand rows 16-byte aligned: a row is read as eight broadcast float4
 struct WinBwdArgs {
   int B, C, H, W, heads, shift, coupled, chunks;
   float scale;
@@ -475,7 +543,7 @@ struct WinBwdArgs {
 };
 
 __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
-  __shared__ float Qs[64 * WB_LD], Ks[64 * WB_LD], Vs[64 * WB_LD], Gs[64 * WB_LD];
+  __shared__ __attribute__((aligned(16))) float Qs[64 * WB_LD], Ks[64 * WB_LD], Vs[64 * WB_LD], Gs[64 * WB_LD];
   __shared__ float T[64 * WB_TLD];
   __shared__ float ts[232];
   const int lane = threadIdx.x, chunk = blockIdx.x, h = blockIdx.y;
@@ -524,30 +592,50 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       rid = 3 * rh + rw;
     }
     __syncthreads();
-    float q[32], g[32];
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      q[e] = Qs[lane * WB_LD + e];
-      g[e] = Gs[lane * WB_LD + e];
-    }
+    // scores and dA in two sweeps, so that only one of q / dO is live next to the 2 x 64 row registers
     float sc[64], da[64];
     float mx = -INFINITY;
+    {
+      float q[32];
 #pragma unroll
-    for (int m = 0; m < 64; ++m) {
-      float s = 0.f, d = 0.f;
+      for (int e = 0; e < 32; ++e) q[e] = Qs[lane * WB_LD + e];
 #pragma unroll
-      for (int e = 0; e < 32; ++e) {
-        s = fmaf(q[e], Ks[m * WB_LD + e], s);
-        d = fmaf(g[e], Vs[m * WB_LD + e], d);
+      for (int m = 0; m < 64; ++m) {
+        float s = 0.f;
+        const float4* __restrict__ kr = reinterpret_cast<const float4*>(&Ks[m * WB_LD]);
+#pragma unroll
+        for (int e4 = 0; e4 < 8; ++e4) {
+          const float4 kv = kr[e4];
+          s = fmaf(q[4 * e4 + 0], kv.x, s); s = fmaf(q[4 * e4 + 1], kv.y, s);
+          s = fmaf(q[4 * e4 + 2], kv.z, s); s = fmaf(q[4 * e4 + 3], kv.w, s);
+        }
+        s += ts[(ty - (m >> 3) + 7) * 15 + (tx - (m & 7) + 7)];
+        if (a.shift) {
+          const int rid_m = __shfl(rid, m);
+          if (rid_m != rid) s += -100.0f;
+        }
+        sc[m] = s;
+        mx = fmaxf(mx, s);
+        __builtin_amdgcn_sched_barrier(0);   // keep the next rows' LDS reads from being hoisted (register pressure)
       }
-      s += ts[(ty - (m >> 3) + 7) * 15 + (tx - (m & 7) + 7)];
-      if (a.shift) {
-        const int rid_m = __shfl(rid, m);
-        if (rid_m != rid) s += -100.0f;
+    }
+    {
+      float g[32];
+#pragma unroll
+      for (int e = 0; e < 32; ++e) g[e] = Gs[lane * WB_LD + e];
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        float d = 0.f;
+        const float4* __restrict__ vr = reinterpret_cast<const float4*>(&Vs[m * WB_LD]);
+#pragma unroll
+        for (int e4 = 0; e4 < 8; ++e4) {
+          const float4 vv = vr[e4];
+          d = fmaf(g[4 * e4 + 0], vv.x, d); d = fmaf(g[4 * e4 + 1], vv.y, d);
+          d = fmaf(g[4 * e4 + 2], vv.z, d); d = fmaf(g[4 * e4 + 3], vv.w, d);
+        }
+        da[m] = d;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      sc[m] = s;
-      da[m] = d;
-      mx = fmaxf(mx, s);
     }
     float sum = 0.f;
 #pragma unroll
@@ -562,6 +650,8 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
     }
     g0 += D;
     g1 += t1;
+    // (compiler-level barrier: the K rows are read again below rather than kept in registers since the score loop)
+    asm volatile("" ::: "memory");
     float dq[32];
 #pragma unroll
     for (int e = 0; e < 32; ++e) dq[e] = 0.f;
@@ -571,8 +661,14 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       T[lane * WB_TLD + m] = w0 * p0 + w1 * r * r;                      // A[n][m]
       const float ds = w0 * p0 * (da[m] - D) + 2.0f * w1 * r * da[m];
       da[m] = ds;
+      const float4* __restrict__ kr = reinterpret_cast<const float4*>(&Ks[m * WB_LD]);
 #pragma unroll
-      for (int e = 0; e < 32; ++e) dq[e] = fmaf(ds, Ks[m * WB_LD + e], dq[e]);
+      for (int e4 = 0; e4 < 8; ++e4) {
+        const float4 kv = kr[e4];
+        dq[4 * e4 + 0] = fmaf(ds, kv.x, dq[4 * e4 + 0]); dq[4 * e4 + 1] = fmaf(ds, kv.y, dq[4 * e4 + 1]);
+        dq[4 * e4 + 2] = fmaf(ds, kv.z, dq[4 * e4 + 2]); dq[4 * e4 + 3] = fmaf(ds, kv.w, dq[4 * e4 + 3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     {
       float* __restrict__ dqp = a.dq + (long)img * a.dqkv_bs + (long)(h * 32) * P + pq;
@@ -586,8 +682,13 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       for (int e = 0; e < 32; ++e) dv[e] = 0.f;
       for (int n = 0; n < 64; ++n) {
         const float av = T[n * WB_TLD + lane];
+        const float4* __restrict__ gr = reinterpret_cast<const float4*>(&Gs[n * WB_LD]);
 #pragma unroll
-        for (int e = 0; e < 32; ++e) dv[e] = fmaf(av, Gs[n * WB_LD + e], dv[e]);
+        for (int e4 = 0; e4 < 8; ++e4) {
+          const float4 gv = gr[e4];
+          dv[4 * e4 + 0] = fmaf(av, gv.x, dv[4 * e4 + 0]); dv[4 * e4 + 1] = fmaf(av, gv.y, dv[4 * e4 + 1]);
+          dv[4 * e4 + 2] = fmaf(av, gv.z, dv[4 * e4 + 2]); dv[4 * e4 + 3] = fmaf(av, gv.w, dv[4 * e4 + 3]);
+        }
       }
       float* __restrict__ dvp = a.dv + (long)img * a.dqkv_bs + (long)(h * 32) * P + pq;
 #pragma unroll
@@ -616,8 +717,13 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       for (int e = 0; e < 32; ++e) dk[e] = 0.f;
       for (int n = 0; n < 64; ++n) {
         const float sv = T[n * WB_TLD + lane];
+        const float4* __restrict__ qr = reinterpret_cast<const float4*>(&Qs[n * WB_LD]);
 #pragma unroll
-        for (int e = 0; e < 32; ++e) dk[e] = fmaf(sv, Qs[n * WB_LD + e], dk[e]);
+        for (int e4 = 0; e4 < 8; ++e4) {
+          const float4 qv = qr[e4];
+          dk[4 * e4 + 0] = fmaf(sv, qv.x, dk[4 * e4 + 0]); dk[4 * e4 + 1] = fmaf(sv, qv.y, dk[4 * e4 + 1]);
+          dk[4 * e4 + 2] = fmaf(sv, qv.z, dk[4 * e4 + 2]); dk[4 * e4 + 3] = fmaf(sv, qv.w, dk[4 * e4 + 3]);
+        }
       }
       float* __restrict__ dkp = a.dk + (long)img_k * a.dqkv_bs + (long)(hk * 32) * P + pk;
 #pragma unroll
@@ -703,12 +809,15 @@ void* train_scratch(int slot, size_t bytes) {
 
 inline long dense(long bs, long c, long p) { return bs ? bs : c * p; }
 
+// Per-kernel device time of the training operators (HIP events around every launch), for the calling thread.
+thread_local KernelClock g_train_clock;
+
 void conv_dw_launch(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, float* db, int B, int M, int K,
                     int P, const ConvGeom* cg, int accumulate, hipStream_t s) {
   const int tm = (M + NT_T - 1) / NT_T, tk = (K + NT_T - 1) / NT_T;
   const long chunks = (long)((P + NT_PX - 1) / NT_PX) * B;
-  // enough slabs to fill the chip, at least 16 chunks (4 per wave) each
-  int slabs = (int)std::max<long>(1, std::min<long>(chunks / 16, (1024 + tm * tk - 1) / (tm * tk)));
+  // enough slabs to fill the chip (two workgroups per CU and then some), at least 16 chunks (4 per wave) each
+  int slabs = (int)std::max<long>(1, std::min<long>(chunks / 16, (2048 + tm * tk - 1) / (tm * tk)));
   const int cps = (int)((chunks + slabs - 1) / slabs);
   slabs = (int)((chunks + cps - 1) / cps);
   float* part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float)));
@@ -737,6 +846,34 @@ using namespace jirf;
 
 extern "C" {
 
+int jirf_train_kernel_timing(int enable) {
+  return guarded_t([&] {
+    g_train_clock.enabled = enable != 0;
+    g_train_clock.begin_forward();
+    set_current_clock(enable ? &g_train_clock : nullptr);
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_kernel_times(const char** names_out, float* ms_out, double* flops_out, double* bytes_out, int* launches_out,
+                            int capacity, int* n_out) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(n_out, JIRF_EINVAL, "null argument");
+    g_train_clock.collect();
+    g_train_clock.begin_forward();
+    const auto& agg = g_train_clock.agg;
+    *n_out = (int)agg.size();
+    for (int i = 0; i < (int)agg.size() && i < capacity; ++i) {
+      if (names_out) names_out[i] = agg[i].name;
+      if (ms_out) ms_out[i] = agg[i].ms;
+      if (flops_out) flops_out[i] = agg[i].flops;
+      if (bytes_out) bytes_out[i] = agg[i].bytes;
+      if (launches_out) launches_out[i] = agg[i].launches;
+    }
+    return JIRF_OK;
+  });
+}
+
 int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, long n, float loss_weight,
                          double* loss_host, void* stream) {
   return guarded_t([&] {
@@ -744,9 +881,12 @@ int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, lo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<long>(1024, (n + 255) / 256);
     double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double)));
-    hipLaunchKernelGGL(smooth_l1_kernel, dim3(blocks), dim3(256), 0, s, pred, target, grad, n,
-                       loss_weight / (float)n, pd);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, pd + blocks);
+    {
+      Scope sc("train_smooth_l1", 6.0 * n, 12.0 * n, s);
+      hipLaunchKernelGGL(smooth_l1_kernel, dim3(blocks), dim3(256), 0, s, pred, target, grad, n,
+                         loss_weight / (float)n, pd);
+      hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, pd + blocks);
+    }
     JIRF_HIP_CHECK(hipGetLastError());
     double tot = 0.0;
     JIRF_HIP_CHECK(hipMemcpyAsync(&tot, pd + blocks, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -762,8 +902,11 @@ int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<long>(1024, (n + 255) / 256);
     double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double)));
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, pd);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, out_dev ? out_dev : pd + blocks);
+    {
+      Scope sc("train_grad_sumsq", 2.0 * n, 4.0 * n, s);
+      hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, pd);
+      hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, out_dev ? out_dev : pd + blocks);
+    }
     JIRF_HIP_CHECK(hipGetLastError());
     if (out_host) {
       JIRF_HIP_CHECK(hipMemcpyAsync(out_host, out_dev ? out_dev : pd + blocks, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -780,6 +923,7 @@ int jirf_train_adam_step(float* p, const float* g, float* m, float* v, long n, c
     JIRF_REQUIRE(max_norm <= 0.f || sumsq_dev, JIRF_EINVAL, "adam_step: clipping needs the gradient's sum of squares");
     const float bc0 = 1.0f - std::pow(beta0, (float)step), bc1 = 1.0f - std::pow(beta1, (float)step);
     const int blocks = (int)std::min<long>(4096, (n + 255) / 256);
+    Scope sc("train_adam", 12.0 * n, 28.0 * n, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
                        sumsq_dev, max_norm, lr, beta0, beta1, eps, bc0, bc1, torch_form);
     JIRF_HIP_CHECK(hipGetLastError());
@@ -827,8 +971,11 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
     const int Mp = (M + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD, Kp = (g.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
     float* wt = static_cast<float*>(train_scratch(SC_PACK, ((size_t)Kp * Mp + Mp) * sizeof(float)));
     const int kind = w_kind == JIRF_W_FWD ? 0 : w_kind == JIRF_W_BWD_DATA ? 1 : w_kind == JIRF_W_DECONV ? 2 : 4;
-    hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)(((long)Kp * Mp + 255) / 256)), dim3(256), 0, s, w, wt, kind, M,
-                       Cin, taps, g.K, Kp, Mp);
+    {
+      Scope sc("train_pack_weights", 0.0, 4.0 * ((double)Kp * Mp + (double)g.K * M), s);
+      hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)(((long)Kp * Mp + 255) / 256)), dim3(256), 0, s, w, wt, kind, M,
+                         Cin, taps, g.K, Kp, Mp);
+    }
     const float* bias_use = bias;
     if (bias && w_kind == JIRF_W_DECONV) {
       float* b4 = wt + (size_t)Kp * Mp;
@@ -898,18 +1045,22 @@ int jirf_train_layernorm_bwd(const float* x, long x_bs, const float* dy, long dy
     JIRF_REQUIRE(x && dy && w && dx && dw && B > 0 && C > 0 && P > 0 && (kind == 1 || kind == 2), JIRF_EINVAL,
                  "layernorm_bwd: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int gx = (P + 255) / 256;
+    const int gx = (P + 63) / 64;
     const int slots = gx * B;
     double* pw = static_cast<double*>(train_scratch(SC_PART_A, (size_t)slots * C * sizeof(double)));
     double* pb = static_cast<double*>(train_scratch(SC_PART_B, (size_t)slots * C * sizeof(double)));
-    Scope sc(intern_label("train_layernorm_bwd C%d P%d", C, P), 12.0 * B * C * (double)P, 4.0 * B * C * (double)P * 7, s);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(gx, B), dim3(256), 256 * sizeof(double), s, x, dense(x_bs, C, P), dy,
-                       dense(dy_bs, C, P), w, add, dense(add_bs, C, P), dx, dense(dx_bs, C, P), pw, pb, C, P,
-                       kind == 1 ? 1 : 0);
-    hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((C + 255) / 256), dim3(256), 0, s, pw, (long)C, slots, dw, accumulate);
-    if (db && kind == 1)
-      hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((C + 255) / 256), dim3(256), 0, s, pb, (long)C, slots, db,
-                         accumulate);
+    Scope sc(intern_label("train_layernorm_bwd C%d P%d", C, P), 12.0 * B * C * (double)P,
+             4.0 * B * C * (double)P * (add ? 4 : 3), s);
+    if (slots < 512)
+      hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(gx, B), dim3(1024), 0, s, x, dense(x_bs, C, P), dy,
+                         dense(dy_bs, C, P), w, add, dense(add_bs, C, P), dx, dense(dx_bs, C, P), pw, pb, C, P,
+                         kind == 1 ? 1 : 0);
+    else
+      hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(gx, B), dim3(256), 0, s, x, dense(x_bs, C, P), dy,
+                         dense(dy_bs, C, P), w, add, dense(add_bs, C, P), dx, dense(dx_bs, C, P), pw, pb, C, P,
+                         kind == 1 ? 1 : 0);
+    hipLaunchKernelGGL(reduce_cols_d_kernel, dim3(C), dim3(256), 0, s, pw, C, slots, dw, accumulate);
+    if (db && kind == 1) hipLaunchKernelGGL(reduce_cols_d_kernel, dim3(C), dim3(256), 0, s, pb, C, slots, db, accumulate);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });
@@ -993,11 +1144,13 @@ int jirf_train_dwconv3x3_bwd_weight(const float* x, long x_bs, const float* dy, 
     JIRF_REQUIRE(x && dy && dw && B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "dwconv3x3_bwd_weight: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long P = (long)H * W;
-    double* part = static_cast<double*>(train_scratch(SC_PART_A, (size_t)B * C * 10 * sizeof(double)));
+    // at least 2048 pixels per workgroup, and enough workgroups to fill the chip
+    const int slabs = (int)std::max<long>(1, std::min<long>(P / 2048, (4096 + (long)B * C - 1) / ((long)B * C)));
+    double* part = static_cast<double*>(train_scratch(SC_PART_A, (size_t)B * slabs * C * 10 * sizeof(double)));
     Scope sc(intern_label("train_dwconv_dw C%d H%d W%d", C, H, W), 20.0 * B * C * (double)P, 8.0 * B * C * (double)P, s);
-    hipLaunchKernelGGL(dwconv_dw_kernel, dim3(C, B), dim3(256), 0, s, x, dense(x_bs, C, P), dy, dense(dy_bs, C, P), part,
-                       C, H, W);
-    hipLaunchKernelGGL(dwconv_dw_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, B, C, dw, db,
+    hipLaunchKernelGGL(dwconv_dw_kernel, dim3(C, B * slabs), dim3(256), 0, s, x, dense(x_bs, C, P), dy, dense(dy_bs, C, P),
+                       part, C, H, W, slabs);
+    hipLaunchKernelGGL(dwconv_dw_reduce_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, B * slabs, C, dw, db,
                        accumulate);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;

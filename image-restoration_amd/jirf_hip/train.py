@@ -55,6 +55,37 @@ def _vp(a: Optional[int]):
     return None if a is None else C.c_void_p(a)
 
 
+def average_flat_gradients(g: torch.Tensor, group=None) -> None:
+    """The data-parallel exchange of the step: one all-reduce (sum) of the flat gradient buffer over the ranks of
+    `group`, then the division by their number - the mean that Jittor's optimizer takes under MPI.  In place; a
+    no-op without an initialised process group or with a single rank.  Works on any device the backend of the
+    group serves (RCCL for GPU tensors, gloo for CPU tensors)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        g.mul_(1.0 / world)
+
+
+def broadcast_flat_parameters(p: torch.Tensor, group=None, src: int = 0) -> None:
+    """The one-time parameter broadcast at start-up, so that every replica steps from the same weights."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(p, src=src, group=group)
+
+
+def reduce_loss(loss: float, device, group=None) -> float:
+    """reduce_loss_dict (basicsr/models/base_model.py:287-305): the logged loss is the mean over the ranks."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return loss
+    t = torch.tensor([loss], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)
+
+
 class AstTrainStep:
     """Holds the training state of one AST replica on one GPU and runs optimisation steps on it."""
 
@@ -397,14 +428,23 @@ class AstTrainStep:
 
     # ---- the step (image_restoration_model.py:235-276) -------------------------------------------------------------
     def average_gradients(self) -> None:
-        """The data-parallel exchange: one all-reduce of the flat gradient buffer, then the division by the number of
-        ranks (the mean Jittor's optimizer takes under MPI)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self.group)
-            if world > 1:
-                dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=self.group)
-                self.g.mul_(1.0 / world)
+        average_flat_gradients(self.g, self.group)
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        broadcast_flat_parameters(self.p, self.group, src)
+
+    def kernel_timing(self, on: bool) -> None:
+        check(self.L.jirf_train_kernel_timing(int(on)))
+
+    def kernel_times(self) -> List[dict]:
+        cap = 1024
+        names = (C.c_char_p * cap)()
+        ms, fl, by = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        ln = (C.c_int * cap)()
+        n = C.c_int()
+        check(self.L.jirf_train_kernel_times(names, ms, fl, by, ln, cap, C.byref(n)))
+        return [dict(name=names[i].decode(), ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i]), launches=int(ln[i]))
+                for i in range(min(n.value, cap))]
 
     def apply_update(self) -> None:
         """clip_grad_norm(0.01) when enabled and past the first iteration (image_restoration_model.py:269-270), then
@@ -424,4 +464,5 @@ class AstTrainStep:
         self.output = pred
         self.average_gradients()
         self.apply_update()
+        self.log_loss = reduce_loss(loss, self.device, self.group)
         return loss

@@ -223,6 +223,14 @@ int jirf_op_psnr_stats(const float* a, const float* b, int C, int H, int W, int 
  *      process ends): training calls that overlap on one device race.  Every reduction has a fixed order (no
  *      atomics): a step is reproducible. */
 
+/* Per-kernel device time of the training operators called from this thread (HIP events around every launch;
+ * serialises nothing but adds two events per launch).  jirf_train_kernel_times waits for the recorded launches,
+ * returns the totals per label since the last call (names_out receives pointers to static strings) and starts
+ * a new interval.  No counterpart in the reference. */
+int jirf_train_kernel_timing(int enable);
+int jirf_train_kernel_times(const char** names_out, float* ms_out, double* flops_out, double* bytes_out, int* launches_out,
+                            int capacity, int* n_out);
+
 /* Pixel loss of the shipped configurations: "L1Loss" is nn.smooth_l1_loss with mean reduction
  * (basicsr/models/losses/losses.py:12-14,44-52).  *loss_host = loss_weight * mean(l); grad (or NULL) receives
  * d loss / d pred = loss_weight * clamp(pred - target, -1, 1) / n.  Synchronises `stream`. */

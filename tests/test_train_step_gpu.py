@@ -127,6 +127,29 @@ def test_training_forward_equals_the_inference_forward():
         assert max_abs(pred.cpu().numpy(), y.cpu().numpy()) < 2e-5, mode
 
 
+def test_gradient_mean_over_two_shards_equals_the_batch_gradient():
+    """What the data-parallel step relies on: with per-image semantics the gradient of the mean loss over a batch is
+    the mean of the gradients of its shards (here the two halves a 2-rank job would hold), so averaging the flat
+    gradient buffers over the ranks reproduces the single-GPU step on the global batch."""
+    from jirf_hip.train import AstTrainStep
+    cfg = _cfg()
+    sd = _state(cfg, 4)
+    lq, gt = _data(2, 128, 21)
+    tr = AstTrainStep(cfg, sd, coupled=False)
+    loss, _ = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt))
+    g_all = tr.g.clone()
+    parts, losses = [], []
+    for i in range(2):
+        tr.g.zero_()
+        li, _ = tr.forward_backward(torch.from_numpy(lq[i:i + 1]), torch.from_numpy(gt[i:i + 1]))
+        parts.append(tr.g.clone())
+        losses.append(li)
+    mean = 0.5 * (parts[0] + parts[1])
+    scale = float(g_all.abs().max())
+    assert float((mean - g_all).abs().max()) < 1e-5 * scale
+    assert abs(0.5 * sum(losses) - loss) < 1e-6 * abs(loss)
+
+
 def test_a_few_steps_reduce_the_loss():
     from jirf_hip.train import AstTrainStep
     cfg = _cfg()
