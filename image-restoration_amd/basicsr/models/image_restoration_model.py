@@ -1,8 +1,13 @@
-"""Validation half of the reference's `ImageCleanModel` (basicsr/models/image_restoration_model.py:125-156,
-230-233, 278-429): build network_g from the option tree, load its checkpoint, run `pad_test` /
-`nonpad_test` over a data loader and average the metrics the YAML names.  The network runs in
-libjirf_hip.so; inputs are moved to the GPU once and the restored image stays there until a metric or an
-image file needs it.  The training half (losses, optimiser, EMA) is not part of this package."""
+"""The reference's `ImageCleanModel` (basicsr/models/image_restoration_model.py:125-156, 230-233, 278-429): build
+network_g from the option tree, load its checkpoint, run `pad_test` / `nonpad_test` over a data loader and
+average the metrics the YAML names.  The network runs in libjirf_hip.so; inputs are moved to the GPU once and
+the restored image stays there until a metric or an image file needs it.
+
+Of the training half (:158-276) the optimisation step is provided for `network_g: {type: AST}` with the shipped
+settings (pixel loss L1Loss = smooth-L1 mean, Adam, use_grad_clip): `is_train: true` builds a
+jirf_hip.train.AstTrainStep and `optimize_parameters` runs forward, loss, backward, the gradient average over
+the ranks, clip and update on the GPU.  Mixing augmentation, the FFT loss, EMA and the learning-rate schedulers
+are not provided (set `lr` per iteration through `set_learning_rate`)."""
 from __future__ import annotations
 
 import logging
@@ -27,8 +32,6 @@ class ImageCleanModel:
     def __init__(self, opt):
         self.opt = opt
         self.is_train = bool(opt.get("is_train", False))
-        if self.is_train:
-            raise NotImplementedError("ImageCleanModel: only the validation / test path is provided")
         self.device = torch.device("cuda", int(opt.get("device", 0)))
         self.net_g = define_network(deepcopy(opt["network_g"])).cuda(self.device.index)
         path_opt = opt.get("path") or {}
@@ -38,12 +41,67 @@ class ImageCleanModel:
                               param_key=path_opt.get("param_key", "params"))
         self.net_g.eval()
         self.metric_results = {}
+        if self.is_train:
+            self.init_training_settings()
+
+    # ---- training (:158-276), AST only -------------------------------------------------------------------------
+    def init_training_settings(self):
+        from jirf_hip.train import AstTrainStep
+        net_opt = dict(self.opt["network_g"])
+        if net_opt.pop("type") != "AST":
+            raise NotImplementedError("ImageCleanModel: the optimisation step is provided for network_g.type == 'AST' only")
+        train_opt = self.opt["train"]
+        if train_opt.get("ema_decay", 0) > 0 or train_opt.get("fft_loss_opt") or \
+                (train_opt.get("mixing_augs") or {}).get("mixup", False):
+            raise NotImplementedError("ImageCleanModel: EMA, the FFT loss and mixing augmentation are not provided")
+        pix = dict(train_opt.get("pixel_opt") or {})
+        if pix.get("type") != "L1Loss" or pix.get("reduction", "mean") != "mean":
+            raise ValueError("pixel loss are None." if not pix else f"pixel loss {pix} is not provided (L1Loss, mean)")
+        if not self.net_g.state_dict():
+            # no checkpoint to start from: seeded random weights in the reference's key layout (the reference draws
+            # its initial weights from Jittor's generator, whose stream cannot be reproduced here)
+            from jirf_hip.synthetic import make_state
+            self.net_g.load_state_dict(make_state("AST", net_opt, seed=int(self.opt.get("manual_seed", 0) or 0)), strict=False)
+        optim = dict(train_opt["optim_g"])
+        if optim.pop("type") != "Adam" or optim.get("weight_decay", 0):
+            raise NotImplementedError("optimizer is not supperted yet (Adam without weight decay is)")
+        self.train_step = AstTrainStep(net_opt, self.net_g.state_dict(), device=self.device.index,
+                                       lr=float(optim.get("lr", 1e-3)), betas=tuple(optim.get("betas", (0.9, 0.999))),
+                                       eps=float(optim.get("eps", 1e-8)),
+                                       use_grad_clip=bool(train_opt.get("use_grad_clip", False)),
+                                       loss_weight=float(pix.get("loss_weight", 1.0)))
+        self.train_step.broadcast_parameters()
+        self.log_dict = OrderedDict()
+
+    def set_learning_rate(self, lr: float):
+        self.train_step.lr = float(lr)
+
+    def feed_train_data(self, data):                 # :222-228 (no mixing augmentation)
+        self.feed_data(data)
+
+    def optimize_parameters(self, current_iter):     # :235-276
+        self.train_step.optimize_parameters(self.lq, self.gt, current_iter)
+        self.output = self.train_step.output
+        self.log_dict = OrderedDict(l_pix=self.train_step.log_loss)
+        self._net_is_stale = True
+
+    def get_current_log(self):
+        return self.log_dict
+
+    def sync_network(self):
+        """Copies the trained weights into net_g (validation and save_network read them from there)."""
+        if getattr(self, "_net_is_stale", False):
+            self.net_g.load_state_dict(self.train_step.state_dict())
+            self.net_g.cuda(self.device.index).eval()
+            self._net_is_stale = False
 
     # base_model.py:228-258
     def load_network(self, net, load_path, strict=True, param_key="params"):
         return checkpoint.load_network(net, load_path, strict, param_key)
 
     def save_network(self, net, save_path, param_key="params"):
+        if self.is_train and net is self.net_g:
+            self.sync_network()
         return checkpoint.save_network(net, save_path, param_key)
 
     def _to_device(self, x) -> torch.Tensor:
@@ -70,6 +128,8 @@ class ImageCleanModel:
     def nonpad_test(self, img=None):                 # :293-310
         if img is None:
             img = self.lq
+        if self.is_train:
+            self.sync_network()
         self.net_g.eval()
         pred = self.net_g(img)
         if isinstance(pred, (list, tuple)):

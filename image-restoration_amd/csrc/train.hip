@@ -236,24 +236,25 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restri
   }
 }
 
-// out[e] (+)= sum over slabs, in slab order
+// out[e] (+)= sum over slabs of part[slab][e].  A workgroup owns 16 consecutive outputs; its 16 thread groups add
+// every 16th slab each and the 16 sums meet in LDS in group order (a fixed order: reproducible).
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, long n, int slabs,
                                                            float* __restrict__ out, int accumulate) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  __shared__ float red[16][16];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long e = (long)blockIdx.x * 16 + col;
   float t = 0.f;
-  for (int s = 0; s < slabs; ++s) t += part[(long)s * n + e];
-  out[e] = accumulate ? out[e] + t : t;
+  if (e < n)
+    for (int s = grp; s < slabs; s += 16) t += part[(long)s * n + e];
+  red[grp][col] = t;
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += red[g][col];
+    out[e] = accumulate ? out[e] + v : v;
+  }
 }
-__global__ __launch_bounds__(256) void reduce_parts_d_kernel(const double* __restrict__ part, long n, int slabs,
-                                                             float* __restrict__ out, int accumulate) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  double t = 0.0;
-  for (int s = 0; s < slabs; ++s) t += part[(long)s * n + e];
-  out[e] = accumulate ? out[e] + (float)t : (float)t;
-}
-
 // out[c] (+)= sum over slots of part[slot][c], one workgroup per column: thread t adds slots t, t + 256, ... and
 // the 256 sums meet in a tree of fixed shape, so the result does not depend on timing.
 __global__ __launch_bounds__(256) void reduce_cols_d_kernel(const double* __restrict__ part, int n, int slots,
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void reduce_cols_d_kernel(const double* __rest
 // pixel's first channel (shifted data keeps the one-pass variance as accurate as the two-pass form); the waves'
 // sums meet in LDS and are added in wave order.  Pass 2 writes dx and reduces the parameter gradients
 // dw[c] = sum dy n, db[c] = sum dy over the 64 pixels with cross-lane shuffles: one partial per (workgroup,
-// channel), added up in workgroup order by reduce_parts_d_kernel.  NW = 16 where the plane is small (few
+// channel), added up by reduce_cols_d_kernel.  NW = 16 where the plane is small (few
 // workgroups, many channels each), 4 otherwise.
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
@@ -831,11 +832,9 @@ void conv_dw_launch(const float* dy, long dy_bs, const float* x, long x_bs, floa
     hipLaunchKernelGGL(linear_dw_kernel<false>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart, B,
                        M, K, P, cps, ConvGeom{});
   const long n = (long)M * K;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, n, slabs, dw,
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, n, slabs, dw,
                      accumulate);
-  if (db)
-    hipLaunchKernelGGL(reduce_parts_d_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dbpart, (long)M, slabs, db,
-                       accumulate);
+  if (db) hipLaunchKernelGGL(reduce_cols_d_kernel, dim3(M), dim3(256), 0, s, dbpart, M, slabs, db, accumulate);
   JIRF_HIP_CHECK(hipGetLastError());
 }
 

@@ -25,3 +25,21 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank():
     assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1
     assert rec["unit"] == "MP/s" and rec["value"] > 0 and rec["scaling"] == "weak"
     assert rec["config"]["batch_per_gpu"] == 2
+
+
+def test_training_step_bench_runs_under_the_launcher_with_one_rank():
+    """`bench.py --train-step` the way a multi-GPU run starts it: the process group exists, so the parameter
+    broadcast, the gradient all-reduce (over one rank) and the loss reduce take their RCCL path."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29618", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--train-step", "--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["unit"] == "MP/s" and rec["value"] > 0
+    assert rec["config"]["batch_per_gpu"] == 2 and rec["config"]["gradient_floats"] > 26_000_000
+    assert rec["loss_last"] < rec["loss_first"]

@@ -159,3 +159,43 @@ def test_a_few_steps_reduce_the_loss():
     losses = [tr.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt)) for _ in range(6)]
     print("[AST training step] losses on one fixed batch:", " ".join(f"{x:.5f}" for x in losses))
     assert losses[-1] < losses[0]
+
+
+def test_model_wrapper_runs_the_step_from_the_option_tree(tmp_path):
+    """ImageCleanModel with `is_train: true` and the train block of Enhancement/Options/AST_LOL_v2_synthetic.yml:
+    feed_train_data + optimize_parameters (image_restoration_model.py:222-276) equals AstTrainStep driven directly,
+    validation afterwards sees the updated weights, and what is not provided fails loudly."""
+    from basicsr.models import create_model
+    from jirf_hip import checkpoint
+    from jirf_hip.train import AstTrainStep
+    cfg = _cfg()
+    sd = _state(cfg, 8)
+    ck = tmp_path / "net_g.jth"
+    checkpoint.save({"params": sd}, str(ck))
+    opt = {"name": "t", "model_type": "ImageCleanModel", "is_train": True, "scale": 1, "manual_seed": 100,
+           "network_g": dict(cfg, type="AST"),
+           "path": {"pretrain_network_g": str(ck), "strict_load_g": True},
+           "train": {"total_iter": 150000, "use_grad_clip": True, "mixing_augs": {"mixup": False},
+                     "optim_g": {"type": "Adam", "lr": 2e-4, "betas": [0.9, 0.999]},
+                     "pixel_opt": {"type": "L1Loss", "loss_weight": 1, "reduction": "mean"}}}
+    model = create_model(opt)
+    ref = AstTrainStep(cfg, sd, lr=2e-4, use_grad_clip=True)
+    for it in (1, 2):
+        lq, gt = _data(2, 128, 30 + it)
+        model.feed_train_data({"lq": torch.from_numpy(lq), "gt": torch.from_numpy(gt)})
+        model.optimize_parameters(it)
+        want = ref.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), it)
+        assert abs(model.get_current_log()["l_pix"] - want) < 1e-9
+    assert torch.equal(model.train_step.p, ref.p)                       # same kernels, same order: bit-identical
+    lq, _ = _data(1, 128, 40)
+    model.feed_data({"lq": torch.from_numpy(lq)})
+    model.nonpad_test()
+    _, pred = ref.forward_backward(torch.from_numpy(lq), torch.from_numpy(lq), backward=False)
+    assert max_abs(model.output.cpu().numpy(), pred.cpu().numpy()) < 2e-5
+    model.save_network(model.net_g, str(tmp_path / "net_g_2.jth"))
+    back = checkpoint.load(str(tmp_path / "net_g_2.jth"))["params"]
+    k = "decoderlayer_3.blocks.1.attn.w"
+    assert np.array_equal(np.asarray(back[k]), ref.state_dict()[k]) and not np.array_equal(np.asarray(back[k]), sd[k])
+    bad = dict(opt, network_g=dict(type="HINT"), path={})
+    with pytest.raises(NotImplementedError):
+        create_model(bad)
