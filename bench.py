@@ -465,6 +465,15 @@ def main():
             if a_ != "HINT" and a_ in nets and all(e[0] != a_ for e in extra[extra.index((a_, b_, h_, w_, k_, c_, o_)) + 1:]):
                 del nets[a_]            # free the arena before the next network plans its own
         net.batch_mode = "per_image"
+        # the second half of BASELINE configs[4]: one AST optimisation step (forward, loss, backward, clip, Adam)
+        targs = argparse.Namespace(**dict(vars(args), train_batch=2, size=256, steps=4, warmup=2, no_cpu_baseline=True,
+                                          no_roofline=False, detail=None))
+        trec = train_step_bench(targs, 0, local_rank, 1, False)
+        out["configs"].append({"arch": "AST", "workload": "optimisation step: " + trec["config"]["workload"],
+                               "batch": 2, "height": 256, "width": 256, "steps": 4, "ms_per_step": trec["ms_per_step"],
+                               "ms_per_image": round(trec["ms_per_step"] / 2, 3), "mp_per_s": trec["value"],
+                               "device_ms_per_step": trec.get("device_ms_per_step"),
+                               "dominant_kernel": trec.get("roofline")})
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: one 256x256 image through the oracle on the host cores of this box
