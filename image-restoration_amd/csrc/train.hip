@@ -748,25 +748,32 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
   }
 }
 
-// dtable[i][h] (+)= sum_chunk part_table[h][chunk][i];  d(w) through the two-way softmax of the mixing weights
+// dtable[i][h] (+)= sum_chunk part_table[h][chunk][i]: one workgroup per table entry; the last two workgroups
+// add up the mixing-weight sums G0, G1 over every (head, chunk) slot into gsum[2].  Fixed tree: reproducible.
 __global__ __launch_bounds__(256) void win_attn_bwd_reduce_kernel(const double* __restrict__ part_table,
-                                                                  const double* __restrict__ part_w,
-                                                                  const float* __restrict__ w2, int heads, int chunks,
-                                                                  float* __restrict__ dtable, float* __restrict__ dw2,
-                                                                  int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+                                                                  const double* __restrict__ part_w, int heads,
+                                                                  int chunks, float* __restrict__ dtable,
+                                                                  double* __restrict__ gsum, int accumulate) {
+  __shared__ double red[256];
+  const int e = blockIdx.x;
+  double t = 0.0;
   if (e < 225 * heads) {
     const int i = e / heads, h = e - i * heads;
-    double t = 0.0;
-    for (int c = 0; c < chunks; ++c) t += part_table[((long)h * chunks + c) * 225 + i];
-    dtable[e] = accumulate ? dtable[e] + (float)t : (float)t;
+    for (int c = threadIdx.x; c < chunks; c += 256) t += part_table[((long)h * chunks + c) * 225 + i];
+    t = block_sum_d(t, red);
+    if (threadIdx.x == 0) dtable[e] = accumulate ? dtable[e] + (float)t : (float)t;
+  } else {
+    const int which = e - 225 * heads;
+    for (long s = threadIdx.x; s < (long)heads * chunks; s += 256) t += part_w[s * 2 + which];
+    t = block_sum_d(t, red);
+    if (threadIdx.x == 0) gsum[which] = t;
   }
-  if (e == 0) {
-    double G0 = 0.0, G1 = 0.0;
-    for (long s = 0; s < (long)heads * chunks; ++s) {
-      G0 += part_w[s * 2];
-      G1 += part_w[s * 2 + 1];
-    }
+}
+// d(w) through the two-way softmax of the mixing weights: s = softmax(w), dw_i = s_i (G_i - sum_j G_j s_j)
+__global__ void win_attn_bwd_w_kernel(const double* __restrict__ gsum, const float* __restrict__ w2,
+                                      float* __restrict__ dw2, int accumulate) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double G0 = gsum[0], G1 = gsum[1];
     const double e0 = exp((double)w2[0]), e1 = exp((double)w2[1]);
     const double s0 = e0 / (e0 + e1), s1 = e1 / (e0 + e1);
     const double dot = G0 * s0 + G1 * s1;
@@ -1192,11 +1199,13 @@ int jirf_train_window_attention_bwd(const float* qkv, long qkv_bs, const float* 
     a.dq = dqkv; a.dk = dqkv + (long)C * P; a.dv = dqkv + 2L * C * P;
     a.table = table; a.w2 = w2;
     a.part_table = static_cast<double*>(train_scratch(SC_PART_A, (size_t)heads * a.chunks * 225 * sizeof(double)));
-    a.part_w = static_cast<double*>(train_scratch(SC_PART_B, (size_t)heads * a.chunks * 2 * sizeof(double)));
+    a.part_w = static_cast<double*>(train_scratch(SC_PART_B, ((size_t)heads * a.chunks * 2 + 2) * sizeof(double)));
+    double* gsum = a.part_w + (size_t)heads * a.chunks * 2;
     Scope sc(intern_label("train_win_attn_bwd C%d H%d W%d", C, H, W), 10.0 * 64 * C * (double)P * B, 28.0 * C * (double)P * B, s);
     hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(a.chunks, heads), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(win_attn_bwd_reduce_kernel, dim3((225 * heads + 255) / 256), dim3(256), 0, s, a.part_table,
-                       a.part_w, w2, heads, a.chunks, dtable, dw2, accumulate);
+    hipLaunchKernelGGL(win_attn_bwd_reduce_kernel, dim3(225 * heads + 2), dim3(256), 0, s, a.part_table, a.part_w, heads,
+                       a.chunks, dtable, gsum, accumulate);
+    hipLaunchKernelGGL(win_attn_bwd_w_kernel, dim3(1), dim3(64), 0, s, gsum, w2, dw2, accumulate);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });

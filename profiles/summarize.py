@@ -37,6 +37,21 @@ with open(os.path.join(dst, f"{tag}_hint_b16_kernel_stats_by_grid.csv"), "w") as
     for (k, gx, gy, wx), (n, t) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
         fh.write(f"\"{short(k)}\",{gx},{gy},{wx},{n},{t},{t / n:.0f},{100.0 * t / total:.2f}\n")
 
+# 1b. the same for the AST optimisation step (bench.py --train-step)
+p_train = os.path.join(src, "train_trace", "train_results.db")
+if os.path.exists(p_train):
+    dbt = sqlite3.connect(p_train)
+    agg = {}
+    for name, dur in dbt.execute("select name, duration from kernels"):
+        a = agg.setdefault(name, [0, 0])
+        a[0] += 1
+        a[1] += dur
+    tt = sum(v[1] for v in agg.values())
+    with open(os.path.join(dst, f"{tag}_ast_train_step_kernel_stats.csv"), "w") as fh:
+        fh.write("kernel,calls,total_ns,avg_ns,percent\n")
+        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            fh.write(f"\"{short(k)}\",{n},{t},{t / n:.0f},{100.0 * t / tt:.2f}\n")
+
 # 2. PMC passes over the dominant launch shape alone (profiles/pmc_op.py).
 #    FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts wide streaming
 #    reads at half their size, so reads are doubled (writes are exact).
