@@ -471,6 +471,18 @@ int jirf_op_psnr_stats(const float* a, const float* b, int C, int H, int W, int 
   });
 }
 
+int jirf_op_ssim_work_doubles(int C, int H, int W) { return (int)ssim_work_doubles(C, H, W); }
+
+int jirf_op_ssim_stats(const float* a, const float* b, int C, int H, int W, int crop_border, int quantise, int y_channel,
+                       int blue_plane, float max_value, double* work, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(a && b && work && C > 0 && H > 0 && W > 0 && max_value > 0.f, JIRF_EINVAL, "ssim_stats: bad arguments");
+    launch_ssim_stats(a, b, C, H, W, crop_border, quantise, y_channel, blue_plane, max_value, work,
+                      static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
 int jirf_op_crop_clamp_u8(const float* x, uint8_t* y, int B, int C, int H, int W, int h, int w, void* stream) {
   return guarded([&] {
     JIRF_REQUIRE(x && y && B > 0 && C > 0, JIRF_EINVAL, "crop_clamp_u8: bad arguments");

@@ -168,6 +168,9 @@ void launch_crop_clamp(const float* x, void* y, int B, int C, int H, int W, int 
 size_t psnr_work_doubles();
 void launch_psnr_stats(const float* a, const float* b, int C, int H, int W, int border, int quantise, int y_channel,
                        int blue_plane, double* work, hipStream_t s);
+size_t ssim_work_doubles(int C, int H, int W);
+void launch_ssim_stats(const float* a, const float* b, int C, int H, int W, int border, int quantise, int y_channel,
+                       int blue_plane, float max_value, double* work, hipStream_t s);
 
 // Dense 3x3 (stride 1, zero pad 1) with at most 4 output channels, on the vector ALUs; weights in
 // the GEMM's K-major packing wt[(tap * Cin + c) * Mpad + o].  Returns false (nothing launched)

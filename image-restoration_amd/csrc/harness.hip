@@ -255,4 +255,136 @@ void launch_psnr_stats(const float* a, const float* b, int C, int H, int W, int 
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
+// ---- SSIM statistics (basicsr/metrics/psnr_ssim.py:161-330 of the reference) ----------------------------------
+// calculate_ssim has two forms.  Colour images: one 11 x 11 x 11 Gaussian (sigma 1.5, cv2.getGaussianKernel)
+// over the H x W x C volume with replicate padding on all three axes (_ssim_3d with _generate_3d_gaussian_kernel:
+// the window also runs ACROSS the colour planes), for x, y, x^2, y^2 and x y; test_y_channel: the 2-D window of
+// _ssim_cly (cv2.filter2D, BORDER_REPLICATE) on the BT.601 luma.  Both are separable.  The pass over the colour
+// axis of a C-plane image with replicate padding is a C x C matrix (host-computed, `mix`), applied while the
+// tile is loaded; then 11 taps along x and 11 along y through LDS.  A workgroup owns a 32 x 32 tile of one output
+// plane: 42 x 42 inputs of the five quantities.  fp32 like the reference's convolution; the map is summed in
+// double, per workgroup, and the partials are folded in index order (deterministic).
+constexpr int SSIM_T = 32, SSIM_R = 5, SSIM_IN = SSIM_T + 2 * SSIM_R;
+struct SsimArgs {
+  int C, H, W, border, quantise, y_channel, blue_plane, planes_out;
+  float c1, c2;
+  float g[11];
+  float mix[4][4];
+};
+
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const SsimArgs k, double* __restrict__ part) {
+  __shared__ float in[5][SSIM_IN][SSIM_IN + 1];
+  __shared__ float tmp[5][SSIM_IN][SSIM_T];
+  __shared__ double red[256];
+  const int h = k.H - 2 * k.border, w = k.W - 2 * k.border;
+  const long plane = (long)k.H * k.W;
+  const int x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T, co = blockIdx.z;
+  for (int e = threadIdx.x; e < SSIM_IN * SSIM_IN; e += 256) {
+    const int iy = e / SSIM_IN, ix = e - iy * SSIM_IN;
+    const int yy = min(max(y0 + iy - SSIM_R, 0), h - 1), xx = min(max(x0 + ix - SSIM_R, 0), w - 1);
+    const long at = (long)(yy + k.border) * k.W + xx + k.border;
+    float q[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (k.y_channel) {
+      double ya = 16.0, yb = 16.0;
+      const double wgt[3] = {24.966, 128.553, 65.481};
+      for (int c = 0; c < 3; ++c) {                   // c = 0: blue, 1: green, 2: red
+        const int pl = c == 1 ? 1 : (c == 0 ? k.blue_plane : 2 - k.blue_plane);
+        float va = a[pl * plane + at], vb = b[pl * plane + at];
+        if (k.quantise) { va = quantise_u8(va); vb = quantise_u8(vb); }
+        ya += (double)(va / 255.0f) * wgt[c];
+        yb += (double)(vb / 255.0f) * wgt[c];
+      }
+      const float fa = (float)(ya / 255.0) * 255.0f, fb = (float)(yb / 255.0) * 255.0f;
+      q[0] = fa; q[1] = fb; q[2] = fa * fa; q[3] = fb * fb; q[4] = fa * fb;
+    } else {
+      for (int c = 0; c < k.C; ++c) {
+        const float m = k.mix[co][c];
+        if (m == 0.f) continue;
+        float va = a[c * plane + at], vb = b[c * plane + at];
+        if (k.quantise) { va = quantise_u8(va); vb = quantise_u8(vb); }
+        q[0] = fmaf(m, va, q[0]); q[1] = fmaf(m, vb, q[1]);
+        q[2] = fmaf(m, va * va, q[2]); q[3] = fmaf(m, vb * vb, q[3]); q[4] = fmaf(m, va * vb, q[4]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) in[j][iy][ix] = q[j];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < SSIM_IN * SSIM_T; e += 256) {
+    const int iy = e / SSIM_T, ox = e - iy * SSIM_T;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < 11; ++u) t = fmaf(k.g[u], in[j][iy][ox + u], t);
+      tmp[j][iy][ox] = t;
+    }
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < SSIM_T * SSIM_T; e += 256) {
+    const int oy = e / SSIM_T, ox = e - oy * SSIM_T;
+    if (y0 + oy >= h || x0 + ox >= w) continue;
+    float f[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < 11; ++u) t = fmaf(k.g[u], tmp[j][oy + u][ox], t);
+      f[j] = t;
+    }
+    const float mu1 = f[0], mu2 = f[1];
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = f[2] - mu1_sq, s2 = f[3] - mu2_sq, s12 = f[4] - mu12;
+    acc += (double)(((2.f * mu12 + k.c1) * (2.f * s12 + k.c2)) / ((mu1_sq + mu2_sq + k.c1) * (s1 + s2 + k.c2)));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[4 + ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void ssim_final_kernel(double* __restrict__ work, long n_part, double count) {
+  if (threadIdx.x != 0) return;
+  double t = 0.0;
+  for (long i = 0; i < n_part; ++i) t += work[4 + i];
+  work[0] = t;
+  work[1] = count;
+}
+
+size_t ssim_work_doubles(int C, int H, int W) {
+  return 4 + (size_t)std::max(C, 1) * ((H + SSIM_T - 1) / SSIM_T) * ((W + SSIM_T - 1) / SSIM_T);
+}
+
+void launch_ssim_stats(const float* a, const float* b, int C, int H, int W, int border, int quantise, int y_channel,
+                       int blue_plane, float max_value, double* work, hipStream_t s) {
+  JIRF_REQUIRE(border >= 0 && 2 * border < H && 2 * border < W, JIRF_EINVAL, "ssim: crop_border %d leaves nothing of %dx%d",
+               border, H, W);
+  JIRF_REQUIRE(C >= 1 && C <= 4, JIRF_EINVAL, "ssim: %d planes (1 to 4 are built)", C);
+  JIRF_REQUIRE(!y_channel || C == 3, JIRF_EINVAL, "ssim: the Y channel needs 3 colour planes, got %d", C);
+  JIRF_REQUIRE(blue_plane == 0 || blue_plane == 2, JIRF_EINVAL, "ssim: blue_plane must be 0 or 2");
+  SsimArgs k{};
+  k.C = C; k.H = H; k.W = W; k.border = border; k.quantise = quantise; k.y_channel = y_channel; k.blue_plane = blue_plane;
+  k.planes_out = y_channel ? 1 : C;
+  k.c1 = (0.01f * max_value) * (0.01f * max_value);
+  k.c2 = (0.03f * max_value) * (0.03f * max_value);
+  // cv2.getGaussianKernel(11, 1.5): exp(-(i - 5)^2 / (2 sigma^2)), normalised to sum 1
+  double g[11], gs = 0.0;
+  for (int i = 0; i < 11; ++i) { g[i] = std::exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); gs += g[i]; }
+  for (int i = 0; i < 11; ++i) k.g[i] = (float)(g[i] / gs);
+  for (int co = 0; co < C; ++co)
+    for (int t = 0; t < 11; ++t) k.mix[co][std::min(std::max(co + t - 5, 0), C - 1)] += (float)(g[t] / gs);
+  const int h = H - 2 * border, w = W - 2 * border;
+  const dim3 grid((w + SSIM_T - 1) / SSIM_T, (h + SSIM_T - 1) / SSIM_T, k.planes_out);
+  hipLaunchKernelGGL(ssim_partial_kernel, grid, dim3(256), 0, s, a, b, k, work);
+  JIRF_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(64), 0, s, work, (long)grid.x * grid.y * grid.z,
+                     (double)h * w * k.planes_out);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace jirf

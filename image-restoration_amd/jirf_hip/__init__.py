@@ -91,6 +91,8 @@ SIGNATURES = {
     "jirf_op_crop_clamp_u8": (_i, [_fp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_psnr_work_doubles": (_i, []),
     "jirf_op_psnr_stats": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "jirf_op_ssim_work_doubles": (_i, [_i, _i, _i]),
+    "jirf_op_ssim_stats": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _vp, _vp]),
     "jirf_op_hint_attention_core": (_i, [_fp, _vp, _fp, _i, _fp, _fp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
 }
 

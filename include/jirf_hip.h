@@ -213,6 +213,17 @@ int jirf_op_psnr_work_doubles(void);
 int jirf_op_psnr_stats(const float* a, const float* b, int C, int H, int W, int crop_border, int quantise, int y_channel,
                        int blue_plane, double* work, void* stream);
 
+/* calculate_ssim (basicsr/metrics/psnr_ssim.py:247-330) on two planar [C,H,W] device images (C <= 4): after the call
+ * completes on `stream`, work[0] = sum of the SSIM map, work[1] = number of map values (the metric is their ratio).
+ * Colour form (_ssim_3d, :161-199): one 11 x 11 x 11 Gaussian window (sigma 1.5) over the H x W x C volume with
+ * replicate padding, i.e. also across the colour planes; y_channel != 0: the 2-D window of _ssim_cly (:202-244) on the
+ * BT.601 luma.  max_value is the reference's `1 if img1.max() <= 1 else 255` (:317; 255 for the luma form) and sets
+ * C1 = (0.01 max)^2, C2 = (0.03 max)^2.  crop_border, quantise, y_channel, blue_plane as jirf_op_psnr_stats.
+ * `work` is DEVICE memory of jirf_op_ssim_work_doubles(C, H, W) float64 values, owned by the caller. */
+int jirf_op_ssim_work_doubles(int C, int H, int W);
+int jirf_op_ssim_stats(const float* a, const float* b, int C, int H, int W, int crop_border, int quantise, int y_channel,
+                       int blue_plane, float max_value, double* work, void* stream);
+
 /* ---- training step, device side: the operators of ImageCleanModel.optimize_parameters
  *      (basicsr/models/image_restoration_model.py:235-276) for AST - forward operators that read the weights from
  *      DEVICE memory in the reference's layouts (they change every step), their data and weight gradients, the

@@ -68,3 +68,25 @@ def test_paired_folder_and_option_parsing(tmp_path):
     from basicsr.models import create_model
     with pytest.raises(ValueError, match="is not found"):
         create_model({"model_type": "NoSuchModel"})
+
+
+def test_ssim_oracle_known_answers():
+    """Constant images have a closed form, (2 a b + C1) / (a^2 + b^2 + C1) (the covariance term is 1); identical
+    images give 1; the colour form's window spans the colour planes (a change in one plane moves the others' maps)."""
+    from oracle import metrics_oracle as mo
+    a = np.full((24, 30, 3), 100, np.uint8)
+    b = np.full((24, 30, 3), 140, np.uint8)
+    c1 = (0.01 * 255) ** 2
+    want = (2 * 100 * 140 + c1) / (100 ** 2 + 140 ** 2 + c1)
+    assert abs(mo.calculate_ssim(a, b, 0) - want) < 1e-6
+    assert abs(mo.calculate_ssim(a, b, 2, test_y_channel=False, dtype=np.float64) - want) < 1e-9
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (33, 41, 3)).astype(np.uint8)
+    assert abs(mo.calculate_ssim(x, x, 0) - 1.0) < 1e-6 and abs(mo.calculate_ssim(x, x, 0, test_y_channel=True) - 1.0) < 1e-9
+    y = x.copy()
+    y[..., 0] = 255 - y[..., 0]
+    full = mo.calculate_ssim(x, y, 0)
+    per_plane = np.mean([mo.calculate_ssim(x[..., i], y[..., i], 0) for i in range(3)])
+    assert abs(full - per_plane) > 1e-3
+    g = mo._gaussian_11()
+    assert abs(g.sum() - 1) < 1e-12 and abs(g[5] / g[4] - np.exp(1 / 4.5)) < 1e-12

@@ -60,8 +60,36 @@ def test_psnr_argument_errors():
         calculate_psnr(a, a, 0, input_order="WHC")
     with pytest.raises(Exception, match="crop_border"):
         calculate_psnr(a, a, 4)
-    with pytest.raises(NotImplementedError):
-        calculate_ssim(a, a, 0)
+    with pytest.raises(AssertionError):
+        calculate_ssim(a, np.zeros((8, 9, 3), np.float32), 0)
+    with pytest.raises(ValueError):
+        calculate_ssim(a, a, 0, input_order="WHC")
+
+
+@pytest.mark.parametrize("shape,border,y", [((45, 61, 3), 0, False), ((45, 61, 3), 3, False), ((64, 96, 3), 0, True),
+                                            ((37, 33, 3), 4, True), ((70, 40, 1), 0, False)])
+def test_ssim_matches_oracle(shape, border, y):
+    """calculate_ssim (psnr_ssim.py:247-330): the 3-D window over H x W x C for colour images, the 2-D window on
+    the luma with test_y_channel; uint8-range arrays, [0, 1] float arrays (max_value rule :317) and GPU tensors."""
+    from basicsr.metrics import calculate_ssim
+    rng = np.random.default_rng(sum(shape) + border)
+    a = rng.integers(0, 256, shape).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-25, 26, shape), 0, 255).astype(np.uint8)
+    if shape[2] == 1:
+        a, b = a[..., 0], b[..., 0]
+    want = mo.calculate_ssim(a, b, border, test_y_channel=y)
+    got = calculate_ssim(a, b, border, test_y_channel=y)
+    assert abs(got - want) < 1e-5, (got, want)
+    assert abs(calculate_ssim(a, a, border, test_y_channel=y) - 1.0) < 1e-6
+    if not y and a.ndim == 3:
+        fa, fb = a.astype(np.float32) / 255.0, b.astype(np.float32) / 255.0          # [0, 1] images: C1, C2 from max 1
+        want01 = mo.calculate_ssim(fa, fb, border)
+        assert abs(calculate_ssim(fa, fb, border) - want01) < 1e-5
+        ta = torch.from_numpy(np.ascontiguousarray(fa.transpose(2, 0, 1))).cuda()    # CHW tensor, as a Var is treated
+        tb = torch.from_numpy(np.ascontiguousarray(fb.transpose(2, 0, 1))).cuda()
+        assert abs(calculate_ssim(ta[None], tb[None], border) - want01) < 1e-5
+        chw = calculate_ssim(a.transpose(2, 0, 1), b.transpose(2, 0, 1), border, input_order="CHW")
+        assert abs(chw - want) < 1e-5
 
 
 def test_validation_loop_matches_oracle(tmp_path):
