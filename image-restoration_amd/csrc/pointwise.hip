@@ -772,6 +772,9 @@ bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
   while (R > 1 && (long)((W + 4 * LX - 1) / (4 * LX)) * ((H + RW * R - 1) / (RW * R)) * a.B < 512) R >>= 1;
   const int tiles_x = (W + 4 * LX - 1) / (4 * LX), strips = (H + RW * R - 1) / (RW * R);
   const int n_tasks = tiles_x * strips;
+  // 8 / 16 output channels: one wave carries 128-256 pixels x all channels x all taps; with under ~1000 waves in
+  // the grid (single images) the matrix-core GEMM on a padded tile is faster (AST 256^2, B = 1: 70 -> ~25 us)
+  if (a.M >= 8 && (long)n_tasks * a.B < 1024) return false;
   const dim3 grid((unsigned)((n_tasks + 3) / 4), a.B), block(256);
   const float* res = a.epi == EP_RESID ? a.r.p : nullptr;
 #define JIRF_FEWOUT(CO, RR)                                                                            \

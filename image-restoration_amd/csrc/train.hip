@@ -978,7 +978,7 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
     float* wt = static_cast<float*>(train_scratch(SC_PACK, ((size_t)Kp * Mp + Mp) * sizeof(float)));
     const int kind = w_kind == JIRF_W_FWD ? 0 : w_kind == JIRF_W_BWD_DATA ? 1 : w_kind == JIRF_W_DECONV ? 2 : 4;
     {
-      Scope sc("train_pack_weights", 0.0, 4.0 * ((double)Kp * Mp + (double)g.K * M), s);
+      Scope sc(intern_label("train_pack_weights K%d M%d", g.K, M), 0.0, 4.0 * ((double)Kp * Mp + (double)g.K * M), s);
       hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)(((long)Kp * Mp + 255) / 256)), dim3(256), 0, s, w, wt, kind, M,
                          Cin, taps, g.K, Kp, Mp);
     }
