@@ -274,7 +274,19 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
     JIRF_REQUIRE(ln_kind == 2 || ln_b, JIRF_EINVAL, "ln_conv1x1: WithBias needs ln_b");
     hipStream_t s = static_cast<hipStream_t>(stream);
     WeightPool pool;
-    const PackedW w = pack_upload_1x1(pool, w_host, nullptr, Cout, Cin);
+    // JIRF_OP_LN_FOLD=1 (profiling scripts): the form the networks run - LayerNorm weight and bias folded into the
+    // packed weights and the output bias, the kernel only normalises
+    static const bool fold = std::getenv("JIRF_OP_LN_FOLD") != nullptr;
+    PackedW w;
+    if (fold) {
+      std::vector<float> hw(Cin), hb(Cin, 0.f);
+      JIRF_HIP_CHECK(hipMemcpy(hw.data(), ln_w, (size_t)Cin * 4, hipMemcpyDeviceToHost));
+      if (ln_kind == 1) JIRF_HIP_CHECK(hipMemcpy(hb.data(), ln_b, (size_t)Cin * 4, hipMemcpyDeviceToHost));
+      w = pack_upload_ln_1x1(pool, w_host, nullptr, hw.data(), ln_kind == 1 ? hb.data() : nullptr, Cout, Cin);
+      ln_w = nullptr;
+    } else {
+      w = pack_upload_1x1(pool, w_host, nullptr, Cout, Cin);
+    }
     DeviceBuffer stats;
     stats.ensure((size_t)2 * B * P * 4);
     float* mu = static_cast<float*>(stats.p);
@@ -283,8 +295,8 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
     if (!gemm_ln_inline(Cin)) launch_ln_stats(xv, mu, rstd, B, Cin, P, s);
     GemmArgs g{};
     g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane;
-    g.x = xv; g.y = tv(y, (long)Cout * P); g.imgs_per_group = 1; g.epi = EP_STORE;
-    g.mu = mu; g.rstd = rstd; g.lnw = ln_w; g.lnb = ln_kind == 1 ? ln_b : nullptr; g.ln_center = ln_kind == 1;
+    g.x = xv; g.y = tv(y, (long)Cout * P); g.imgs_per_group = 1; g.epi = EP_STORE; g.bias = w.bias;
+    g.mu = mu; g.rstd = rstd; g.lnw = ln_w; g.lnb = (ln_w && ln_kind == 1) ? ln_b : nullptr; g.ln_center = ln_kind == 1;
     launch_gemm(g, LD_LN, s);
     JIRF_HIP_CHECK(hipStreamSynchronize(s));
     return JIRF_OK;

@@ -553,10 +553,55 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   // The output bias waits in LDS for the epilogues (rows past M as zeros): a vector-memory load there
   // would sit in the same in-order counter as the weight-fragment window and make the epilogue wait for it.
   float* __restrict__ st_bias = st_b + Kp;           // [ceil32(M)] when a.bias
+  // ---- output tiles: bookkeeping and the first weight fragments -------------------------------------------
+  const float* __restrict__ wt = a.wt + (long)b * a.wt_bs;
+  const int n_mt = (M + 31) >> 5;
+  // small grids split the output rows over gridDim.y workgroups (each reloads the pixel tile)
+  const int mt_per = (n_mt + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int item_lo = min((int)blockIdx.y * mt_per, n_mt) * NG;
+  const int n_items = min(((int)blockIdx.y + 1) * mt_per, n_mt) * NG;
+  const int nsteps = Kp >> 1;
+  const int epi = a.epi;
+  // ---- the MFMA loop: a rolling window instead of batches ------------------------------------------
+  // A wave alone on its SIMD must keep the matrix pipe fed (the workgroups sharing the SIMD spend most of
+  // their life in load / LayerNorm / store phases).  So nothing waits at a batch boundary: the weight
+  // fragment of k-step s + 8 is requested into the register that k-step s has just used, the LDS fragment
+  // of k-step s + 2 likewise, and both windows run on into the wave's next item.  Weights are read through
+  // a buffer descriptor: the row advances in the scalar offset, the lane part is one register per item, and
+  // rows past Mpad do not exist in the packed weights, so the column is clamped (such rows are never stored).
+  // The first window is requested here, before the tile is even loaded: the weights do not depend on the tile,
+  // the loads are older than the tile's in the in-order counter, and the first item starts without an L2 round trip.
+  typedef float BV __attribute__((ext_vector_type(TNW)));
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, Kp * a.Mpad * 4, 0x00020000);
+  const int row2 = 2 * a.Mpad * 4;                      // bytes per k-step (two weight rows)
+  auto a_voff = [&](int item) { return (half * a.Mpad + min((item / NG) * 32 + l31, a.Mpad - 1)) * 4; };
+  float a_cur[XS_ABATCH];
+  if (item_lo + wave < n_items) {
+    const int v0 = a_voff(item_lo + wave);
+#pragma unroll
+    for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, v0, i * row2, 0));
+  }
+  // (requested now from clamped addresses, written to LDS just before the barrier: the wait for these loads
+  // would otherwise stand in front of the tile's own loads)
+  constexpr int BIAS_SLOTS = 8;                      // M <= 2048; larger M stages the rest in a plain loop
+  const int bias_n = a.bias ? min(BIAS_SLOTS, (((M + 31) & ~31) + 255) >> 8) : 0;
+  float bias_v[BIAS_SLOTS];
   if (a.bias) {
     const float* __restrict__ bsrc = a.bias + (long)b * a.bias_bs;
-    for (int m = tid; m < ((M + 31) & ~31); m += 256) st_bias[m] = m < M ? bsrc[m] : 0.f;
+#pragma unroll
+    for (int i = 0; i < BIAS_SLOTS; ++i)
+      if (i < bias_n) bias_v[i] = bsrc[min(tid + 256 * i, M - 1)];
   }
+  auto stage_bias = [&]() {
+    if (!a.bias) return;
+    const int mc = (M + 31) & ~31;
+#pragma unroll
+    for (int i = 0; i < BIAS_SLOTS; ++i)
+      if (i < bias_n && tid + 256 * i < mc) st_bias[tid + 256 * i] = tid + 256 * i < M ? bias_v[i] : 0.f;
+    const float* __restrict__ bsrc = a.bias + (long)b * a.bias_bs;
+    for (int m = tid + 256 * BIAS_SLOTS; m < mc; m += 256) st_bias[m] = m < M ? bsrc[m] : 0.f;
+  };
   if constexpr (LOADER == LD_LN && VEC) {
     // LayerNorm in registers.  A wave owns CW groups of four pixels; a lane holds every RW-th channel of
     // its group, so all channels of a pixel live in one wave: mean and variance (two passes over the
@@ -573,6 +618,92 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
     // affine == false: the caller has folded the LayerNorm weight into the GEMM weights and its bias into
     // the output bias (pack_upload_ln_1x1), and the tile is only normalised here
     const bool affine = a.lnw != nullptr, has_b = a.lnb != nullptr;
+    // Fast path (every LayerNorm GEMM of the four networks): K a multiple of 16 (no padding rows), affine folded
+    // into the weights.  The slot count is a compile-time constant, nothing is predicated (columns past the image
+    // are loaded from clamped addresses, normalised like the rest and never stored): about half of the general
+    // path's vector instructions - they are issued while the other workgroups of the CU keep the matrix pipe
+    // busy, which starves them (each costs > 100 cycles).
+    auto ln_fast = [&](auto ns_tag) {
+      constexpr int NS = decltype(ns_tag)::value;
+      // One buffer descriptor per image; the lane part of the address is one register, the row advance of slot u
+      // is a scalar offset: the twelve loads of a K = 96 tile cost three vector instructions of address arithmetic
+      // instead of one 64-bit multiply-add chain each (vector instructions are what this phase is short of).
+      typedef unsigned U4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t x_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)min((long)K * P * 4, 0x7fffffffL), 0x00020000);
+      const int voff = (r0 * P + (col_ok ? p : 0)) * 4;
+      const int row_step = RW * P * 4;
+      // the arithmetic on two-float vectors, so that it compiles to the packed fp32 instructions (v_pk_add_f32,
+      // v_pk_mul_f32, v_pk_fma_f32: half the instruction count), and 1 / sqrt as v_rsq_f32 (1 ulp)
+      typedef float F2 __attribute__((ext_vector_type(2)));
+      F2 va[NS], vb[NS];                     // pixels (0, 1) and (2, 3) of the lane's group, slot u
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const U4 t = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, voff, u * row_step, 0);
+        va[u] = F2{__uint_as_float(t[0]), __uint_as_float(t[1])};
+        vb[u] = F2{__uint_as_float(t[2]), __uint_as_float(t[3])};
+      }
+      XS_STAMP(40);
+      // Sum over the lanes that hold the other channels of the same pixels (lane bits log2(CW) .. 5), on the
+      // vector ALU only: rotations inside a row of 16 lanes (DPP) and the two row-swap instructions of gfx950,
+      // v_permlane16_swap / v_permlane32_swap (with both operands the same value, the swapped pair adds up to
+      // the butterfly sum).  The LDS crossbar (ds_bpermute) is busy with the B fragments of the MFMA waves.
+      auto bits = [](float f) { return __builtin_bit_cast(unsigned, f); };
+      auto flt = [](unsigned u) { return __builtin_bit_cast(float, u); };
+      auto lane_sum1 = [&](float t) {
+        if constexpr (CW == 4) t += flt(__builtin_amdgcn_update_dpp(0, bits(t), 0x124, 0xf, 0xf, false));   // row_ror:4
+        t += flt(__builtin_amdgcn_update_dpp(0, bits(t), 0x128, 0xf, 0xf, false));                          // row_ror:8
+        const auto s16 = __builtin_amdgcn_permlane16_swap(bits(t), bits(t), false, false);
+        t = flt(s16[0]) + flt(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(bits(t), bits(t), false, false);
+        return flt(s32[0]) + flt(s32[1]);
+      };
+      auto lane_sum2 = [&](F2& t) { t = F2{lane_sum1(t[0]), lane_sum1(t[1])}; };
+      F2 sa = va[0], sb = vb[0];
+#pragma unroll
+      for (int u = 1; u < NS; ++u) { sa += va[u]; sb += vb[u]; }
+      XS_STAMP(2);
+      lane_sum2(sa);
+      lane_sum2(sb);
+      XS_STAMP(42);
+      const float inv_k = 1.0f / (float)K;
+      const F2 mua = sa * inv_k, mub = sb * inv_k;
+      F2 qa = F2{0.f, 0.f}, qb = F2{0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const F2 da = va[u] - mua, db = vb[u] - mub;
+        qa = __builtin_elementwise_fma(da, da, qa);
+        qb = __builtin_elementwise_fma(db, db, qb);
+      }
+      lane_sum2(qa);
+      lane_sum2(qb);
+      XS_STAMP(43);
+      const F2 ea = qa * inv_k + 1e-5f, eb = qb * inv_k + 1e-5f;
+      const F2 rsa = F2{__builtin_amdgcn_rsqf(ea[0]), __builtin_amdgcn_rsqf(ea[1])};
+      const F2 rsb = F2{__builtin_amdgcn_rsqf(eb[0]), __builtin_amdgcn_rsqf(eb[1])};
+      const F2 mca = a.ln_center ? mua : F2{0.f, 0.f}, mcb = a.ln_center ? mub : F2{0.f, 0.f};   // BiasFree does not centre
+      float4* __restrict__ xs_w = reinterpret_cast<float4*>(&Xs[r0 * BN + cg * 4]);
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const F2 oa = (va[u] - mca) * rsa, ob = (vb[u] - mcb) * rsb;
+        xs_w[u * (RW * BN / 4)] = make_float4(oa[0], oa[1], ob[0], ob[1]);
+      }
+    };
+    bool fast = false;
+    if (!affine && Kp == K && (long)K * P * 4 < 0x7fffffffL) {
+      fast = true;
+      switch (ns) {
+        case 2: ln_fast(std::integral_constant<int, 2>{}); break;
+        case 3: ln_fast(std::integral_constant<int, 3>{}); break;
+        case 4: ln_fast(std::integral_constant<int, 4>{}); break;
+        case 6: ln_fast(std::integral_constant<int, 6>{}); break;
+        case 8: ln_fast(std::integral_constant<int, 8>{}); break;
+        case 12: ln_fast(std::integral_constant<int, 12>{}); break;
+        case 16: ln_fast(std::integral_constant<int, 16>{}); break;
+        default: fast = false;
+      }
+    }
+    if (!fast) {
     float4 v[NSMAX];
     float g[NSMAX], be[NSMAX];
 #pragma unroll
@@ -649,7 +780,9 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
         *reinterpret_cast<float4*>(&Xs[k * BN + cg * 4]) = o;
       }
     }
+    }
     XS_STAMP(44);
+    stage_bias();
     __syncthreads();
   } else {
     if constexpr (LOADER == LD_LN) {
@@ -706,6 +839,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
         *reinterpret_cast<float4*>(&Xs[k * BN + c4]) = v;
       }
     }
+    stage_bias();
     __syncthreads();
     XS_STAMP(2);
     if constexpr (LOADER == LD_LN) {
@@ -744,27 +878,6 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   }
 
   XS_STAMP(3);
-  // ---- output tiles -----------------------------------------------------------------------------
-  const float* __restrict__ wt = a.wt + (long)b * a.wt_bs;
-  const int n_mt = (M + 31) >> 5;
-  // small grids split the output rows over gridDim.y workgroups (each reloads the pixel tile)
-  const int mt_per = (n_mt + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int item_lo = min((int)blockIdx.y * mt_per, n_mt) * NG;
-  const int n_items = min(((int)blockIdx.y + 1) * mt_per, n_mt) * NG;
-  const int nsteps = Kp >> 1;
-  const int epi = a.epi;
-  // ---- the MFMA loop: a rolling window instead of batches ------------------------------------------
-  // A wave alone on its SIMD must keep the matrix pipe fed (the workgroups sharing the SIMD spend most of
-  // their life in load / LayerNorm / store phases).  So nothing waits at a batch boundary: the weight
-  // fragment of k-step s + 8 is requested into the register that k-step s has just used, the LDS fragment
-  // of k-step s + 2 likewise, and both windows run on into the wave's next item.  Weights are read through
-  // a buffer descriptor: the row advances in the scalar offset, the lane part is one register per item, and
-  // rows past Mpad do not exist in the packed weights, so the column is clamped (such rows are never stored).
-  typedef float BV __attribute__((ext_vector_type(TNW)));
-  const __amdgpu_buffer_rsrc_t w_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, Kp * a.Mpad * 4, 0x00020000);
-  const int row2 = 2 * a.Mpad * 4;                      // bytes per k-step (two weight rows)
-  auto a_voff = [&](int item) { return (half * a.Mpad + min((item / NG) * 32 + l31, a.Mpad - 1)) * 4; };
   auto b_ptr = [&](int item) { return Xs + half * BN + (item % NG) * TNW * 32 + (IL ? TNW * l31 : l31); };
   auto load_b = [&](const float* __restrict__ q) {
     BV v;
@@ -776,12 +889,8 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
     }
     return v;
   };
-  float a_cur[XS_ABATCH];
   BV b_cur[2];
   if (item_lo + wave < n_items) {
-    const int v0 = a_voff(item_lo + wave);
-#pragma unroll
-    for (int i = 0; i < XS_ABATCH; ++i) a_cur[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, v0, i * row2, 0));
     const float* __restrict__ b0 = b_ptr(item_lo + wave);
     b_cur[0] = load_b(b0);
     b_cur[1] = load_b(b0 + 2 * BN);

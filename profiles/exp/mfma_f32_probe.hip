@@ -158,6 +158,56 @@ __global__ __launch_bounds__(256) void mixed(const float* __restrict__ in, float
   if (tid == 0) stamps[blockIdx.x] = Stamp{c1 - c0, r1 - r0};
 }
 
+// Every wave runs the MFMA loop AND, between its own MFMAs, NV independent plain vector instructions per k-step
+// (4 MFMAs): what vector work costs when it sits in the issuing wave's own MFMA shadows, with one or two such
+// waves per SIMD.
+template <int NV>
+__global__ __launch_bounds__(256) void interleaved(const float* __restrict__ in, float* __restrict__ out, int iters,
+                                                   Stamp* stamps) {
+  const int tid = threadIdx.x;
+  float a[8], bq[8], v[8];
+  for (int i = 0; i < 8; ++i) {
+    a[i] = in[(tid * 8 + i) & 0xffff];
+    bq[i] = in[(tid * 8 + i + 4099) & 0xffff];
+    v[i] = in[(tid * 8 + i + 977) & 0xffff];
+  }
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[(i + j) & 7], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NV; ++u) v[u & 7] = fmaf(v[u & 7], 1.0001f, 0.5f);
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x2, NV, 0);
+    }
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][7];
+  for (int i = 0; i < 8; ++i) s += v[i];
+  out[blockIdx.x * 256 + tid] = s;
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) stamps[blockIdx.x] = Stamp{c1 - c0, r1 - r0};
+}
+
+template <int NV>
+void run_interleaved(const float* in, float* out, Stamp* st, int wg_per_cu) {
+  const int iters = 4000, blocks = 256 * wg_per_cu;
+  for (int rep = 0; rep < 10; ++rep) hipLaunchKernelGGL(interleaved<NV>, dim3(blocks), dim3(256), 0, 0, in, out, iters, st);
+  CK(hipDeviceSynchronize());
+  std::vector<Stamp> h(blocks);
+  CK(hipMemcpy(h.data(), st, blocks * sizeof(Stamp), hipMemcpyDeviceToHost));
+  std::vector<double> m;
+  for (int i = 0; i < blocks; ++i) m.push_back((double)h[i].cyc);
+  std::sort(m.begin(), m.end());
+  printf("%d wave(s) per SIMD, %d vector instructions between every 4 MFMAs of the same wave: %.1f cycles per MFMA per wave "
+         "(pipe-bound: %d)\n", wg_per_cu, NV, m[m.size() / 2] / (iters * 32.0), 64 * wg_per_cu);
+}
+
 void run_mixed(const float* in, float* out, Stamp* st, int n_mfma_wg, int b_from_lds) {
   const int iters = 4000, blocks = 256 * (n_mfma_wg + 1);
   for (int rep = 0; rep < 10; ++rep)
@@ -225,6 +275,16 @@ int main() {
   run<2, 4>("32x32x2, B from LDS as the compiler schedules it", 2, in, out, st);
   run<3, 4>("32x32x2, B from LDS one k-step ahead", 1, in, out, st);
   run<3, 4>("32x32x2, B from LDS one k-step ahead", 2, in, out, st);
+  run_interleaved<0>(in, out, st, 1);
+  run_interleaved<2>(in, out, st, 1);
+  run_interleaved<4>(in, out, st, 1);
+  run_interleaved<8>(in, out, st, 1);
+  run_interleaved<16>(in, out, st, 1);
+  run_interleaved<0>(in, out, st, 2);
+  run_interleaved<2>(in, out, st, 2);
+  run_interleaved<4>(in, out, st, 2);
+  run_interleaved<8>(in, out, st, 2);
+  run_interleaved<16>(in, out, st, 2);
   run_mixed(in, out, st, 0, 0);
   run_mixed(in, out, st, 1, 0);
   run_mixed(in, out, st, 2, 0);
