@@ -9,6 +9,8 @@ tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# the isolated launches run the form the networks run (LayerNorm affine folded into the packed weights)
+export JIRF_OP_LN_FOLD=1
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs > $out/bench_under_rocprof.json
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o pmc -- python3 profiles/pmc_op.py
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o pmc -- python3 profiles/pmc_op.py
