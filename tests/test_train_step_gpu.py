@@ -110,6 +110,27 @@ def test_gradients_and_two_steps_against_the_oracle():
     assert err < 0.1 * moved
 
 
+def test_gradients_at_the_benchmark_configuration():
+    """The step `bench.py --train-step` times: full AST (constructor defaults, depths [2] * 9, token_mlp frfn,
+    26.3 M parameters) on two 256 x 256 crops, the literal batched call.  Loss and every parameter's gradient
+    against autograd over the oracle."""
+    from jirf_hip.train import AstTrainStep
+    cfg = so.default_config()
+    sd = _state(cfg, 1)
+    lq, gt = _data(2, 256, 13)
+    loss_ref, pred_ref, g_ref = _oracle_grads(sd, lq, gt, cfg)
+    tr = AstTrainStep(cfg, sd, coupled=True)
+    loss, pred = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt))
+    assert max_abs(pred.cpu().numpy(), pred_ref) < 1e-3
+    assert abs(loss - loss_ref) < 1e-5 * abs(loss_ref)
+    g = tr.grad_dict()
+    worst = max(((float(np.abs(g[k] - w).max()) / max(float(np.abs(w).max()), 1e-12), k) for k, w in g_ref.items()))
+    print(f"[AST training step, full config, 2 x 256 x 256] loss {loss:.6f} (oracle {loss_ref:.6f}); "
+          f"{tr.num_parameters()} parameters, worst relative gradient error {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < REL
+    assert sum(w.size for w in g_ref.values()) == tr.num_parameters() == 26298387
+
+
 def test_training_forward_equals_the_inference_forward():
     from basicsr.models.archs import define_network
     from jirf_hip.train import AstTrainStep
