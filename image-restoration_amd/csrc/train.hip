@@ -521,16 +521,27 @@ __global__ void expand_bias4_kernel(const float* __restrict__ b, float* __restri
 
 // ---- sparse window attention, backward (ast_arch.py:275-318; forward kernel: win_attn.hip) ------------------
 // One wave per workgroup; workgroup (chunk, head) walks over the windows chunk, chunk + chunks, ... of its
-// head.  With lane n = query token n of the 8 x 8 window:
+// head.  For one (window, head), with n = query token, m = key token of the 8 x 8 window:
 //   S[n][m] = q_n k_m + bias + mask,  P0 = softmax_m S,  P1 = relu(S)^2,  A = w0 P0 + w1 P1,  O[n] = sum_m A[n][m] v_m
-//   dA[n][m] = dO_n v_m;   dS = w0 P0 (dA - sum_m dA P0) + 2 w1 relu(S) dA;   dq_n = scale sum_m dS[n][m] k_m
-//   dv_m = sum_n A[n][m] dO_n;   dk_m = sum_n dS[n][m] (scale q_n)            (through an LDS transpose, lane = m)
+//   dA[n][m] = dO_n v_m;   dS = w0 P0 (dA - sum_m dA P0) + 2 w1 relu(S) dA
+//   dq_n = scale sum_m dS[n][m] k_m;   dv_m = sum_n A[n][m] dO_n;   dk_m = sum_n dS[n][m] (scale q_n)
 //   d table[idx(n, m)][head] += dS[n][m];   d(w0, w1) += sum dA (P0, P1)
-// k comes from the (window, head) pair the reference's flattening pairs with this one (see the forward kernel),
-// and dk goes back there: the pairing is a bijection, so every gradient element has one writer.  The table
-// gradient is gathered from the transposed dS tile (lane = table entry: no two lanes ever add to one address),
+// All seven 64 x 64 x 32 / 64 x 32 x 64 products run on fp32 MFMA (32x32x2), following the forward kernel: the
+// q, k, v, dO fragments are loaded from global memory in operand layout (lane = token, k = channel pair), and a
+// lane's fragment serves as A or as B operand alike.  The score tile is formed twice:
+//   "T" form  S^T[m][n] = K Q^T and dA^T = V dO^T (keys in the registers, the lane's column = one query): the
+//             softmax statistics of a query (max, 1 / sum, D = sum_m dA P0) are in-lane sums plus one exchange
+//             with lane ^ 32; dS^T stays in the registers and is the B operand of dQ^T = K^T dS^T (A = K rows
+//             from the wave's LDS tile, lane = channel);
+//   "N" form  S[n][m] = Q K^T and dA = dO V^T (queries in the registers, the lane's column = one key), with
+//             the statistics read back from LDS per query: A and dS in this form are the B operands of
+//             dV^T = dO^T A and dK^T = (scale Q)^T dS (A operands = dO / Q rows from LDS).
+// Recomputing the tile in the other orientation costs 128 MFMAs; it replaces a 64 x 64 transpose through LDS per
+// product.  k comes from the (window, head) pair the reference's flattening pairs with this one (see the forward
+// kernel), and dk goes back there: the pairing is a bijection, so every gradient element has one writer.  The
+// table gradient is gathered from the dS tile in LDS (lane = table entry: no two lanes ever add to one address),
 // kept with the mixing-weight sums per workgroup and added up afterwards in a fixed order.
-constexpr int WB_LD = 36, WB_TLD = 65;   // operand rows 16-byte aligned: a row is read as eight broadcast float4
+constexpr int WB_LD = 40, WB_TLD = 65;   // operand tiles: rows m and m + 4 on disjoint bank halves (as in the forward)
 struct WinBwdArgs {
   int B, C, H, W, heads, shift, coupled, chunks;
   float scale;
@@ -544,10 +555,11 @@ struct WinBwdArgs {
 };
 
 __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float Qs[64 * WB_LD], Ks[64 * WB_LD], Vs[64 * WB_LD], Gs[64 * WB_LD];
+  __shared__ float Ks[64 * WB_LD], Gs[64 * WB_LD], Qs[64 * WB_LD];
   __shared__ float T[64 * WB_TLD];
   __shared__ float ts[232];
-  const int lane = threadIdx.x, chunk = blockIdx.x, h = blockIdx.y;
+  __shared__ float st[3][64];
+  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5, chunk = blockIdx.x, h = blockIdx.y;
   const int H = a.H, W = a.W, heads = a.heads;
   const int nwx = W >> 3, nW = (H >> 3) * nwx;
   const long P = (long)H * W;
@@ -556,8 +568,8 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
   const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
   for (int i = lane; i < 232; i += 64) ts[i] = i < 225 ? a.table[i * heads + h] : 0.f;
   float tacc[4] = {0.f, 0.f, 0.f, 0.f};   // table entries lane, lane + 64, lane + 128, lane + 192
-  const int ty = lane >> 3, tx = lane & 7;
   double g0 = 0.0, g1 = 0.0;
+  auto rowmap = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * half; };   // row of accumulator register r
   for (int gw = chunk; gw < n_win; gw += a.chunks) {
     const int img = gw / nW, w = gw - img * nW;
     const int span = a.coupled ? a.B * nW : nW;
@@ -565,139 +577,194 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
     const int hk = j / span, bk = j - hk * span;
     const int img_k = a.coupled ? bk / nW : img;
     const int wk = a.coupled ? bk - img_k * nW : bk;
-    auto pixel = [&](int win) {
+    auto pixel = [&](int win, int t) {
       const int wy = win / nwx, wx = win - wy * nwx;
-      int y = wy * 8 + ty + a.shift, x = wx * 8 + tx + a.shift;
+      int y = wy * 8 + (t >> 3) + a.shift, x = wx * 8 + (t & 7) + a.shift;
       if (y >= H) y -= H;
       if (x >= W) x -= W;
       return (long)y * W + x;
     };
-    const long pq = pixel(w), pk = pixel(wk);
-    const long oq = (long)img * a.qkv_bs + (long)(h * 32) * P + pq;
-    const long ok = (long)img_k * a.qkv_bs + (long)(hk * 32) * P + pk;
-    const long og = (long)img * a.dout_bs + (long)(h * 32) * P + pq;
-    __syncthreads();   // the previous window's tiles are no longer read
-#pragma unroll 8
-    for (int e = 0; e < 32; ++e) {
-      Qs[lane * WB_LD + e] = a.q[oq + (long)e * P] * a.scale;
-      Ks[lane * WB_LD + e] = a.k[ok + (long)e * P];
-      Vs[lane * WB_LD + e] = a.v[oq + (long)e * P];
-      Gs[lane * WB_LD + e] = a.dout[og + (long)e * P];
+    // ---- operand fragments: token t2 * 32 + l31, channels 2 s + half -------------------------------------------
+    float kf[2][16], qf[2][16], vf[2][16], gf[2][16];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const long pq = pixel(w, t2 * 32 + l31), pk = pixel(wk, t2 * 32 + l31);
+      const float* __restrict__ kp = a.k + (long)img_k * a.qkv_bs + (long)(hk * 32 + half) * P + pk;
+      const float* __restrict__ qp = a.q + (long)img * a.qkv_bs + (long)(h * 32 + half) * P + pq;
+      const float* __restrict__ vp = a.v + (long)img * a.qkv_bs + (long)(h * 32 + half) * P + pq;
+      const float* __restrict__ gp = a.dout + (long)img * a.dout_bs + (long)(h * 32 + half) * P + pq;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        kf[t2][s] = kp[(long)(2 * s) * P];
+        qf[t2][s] = qp[(long)(2 * s) * P] * a.scale;
+        vf[t2][s] = vp[(long)(2 * s) * P];
+        gf[t2][s] = gp[(long)(2 * s) * P];
+      }
     }
-    int rid = 0;
+    __syncthreads();   // the previous window's tiles are no longer read
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int at = (t2 * 32 + l31) * WB_LD + 2 * s + half;
+        Ks[at] = kf[t2][s];
+        Gs[at] = gf[t2][s];
+        Qs[at] = qf[t2][s];
+      }
+    int rid_tok = 0;   // Swin shift-mask region of token `lane` on the shifted grid
     if (a.shift) {
       const int wy = w / nwx, wx = w - wy * nwx;
-      const int sy = wy * 8 + ty, sx = wx * 8 + tx;
+      const int sy = wy * 8 + (lane >> 3), sx = wx * 8 + (lane & 7);
       const int rh = sy < H - 8 ? 0 : (sy < H - a.shift ? 1 : 2);
       const int rw = sx < W - 8 ? 0 : (sx < W - a.shift ? 1 : 2);
-      rid = 3 * rh + rw;
+      rid_tok = 3 * rh + rw;
     }
-    __syncthreads();
-    // scores and dA in two sweeps, so that only one of q / dO is live next to the 2 x 64 row registers
-    float sc[64], da[64];
-    float mx = -INFINITY;
-    {
-      float q[32];
+    __syncthreads();   // the staged tiles; the previous window's statistics are no longer read
+    // ---- "T" form: keys in the registers, the lane's column is a query; one half of the queries at a time ------
 #pragma unroll
-      for (int e = 0; e < 32; ++e) q[e] = Qs[lane * WB_LD + e];
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x16 S[2], dA[2];
 #pragma unroll
-      for (int m = 0; m < 64; ++m) {
-        float s = 0.f;
-        const float4* __restrict__ kr = reinterpret_cast<const float4*>(&Ks[m * WB_LD]);
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-          const float4 kv = kr[e4];
-          s = fmaf(q[4 * e4 + 0], kv.x, s); s = fmaf(q[4 * e4 + 1], kv.y, s);
-          s = fmaf(q[4 * e4 + 2], kv.z, s); s = fmaf(q[4 * e4 + 3], kv.w, s);
+        for (int r = 0; r < 16; ++r) { S[mt][r] = 0.f; dA[mt][r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          S[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[mt][s], qf[nt][s], S[mt], 0, 0, 0);
+          dA[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[mt][s], gf[nt][s], dA[mt], 0, 0, 0);
         }
-        s += ts[(ty - (m >> 3) + 7) * 15 + (tx - (m & 7) + 7)];
-        if (a.shift) {
-          const int rid_m = __shfl(rid, m);
-          if (rid_m != rid) s += -100.0f;
+      const int n = nt * 32 + l31;
+      const int ny = n >> 3, nx = n & 7;
+      const int rid_n = __shfl(rid_tok, n);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mt * 32 + rowmap(r);
+          float sc = S[mt][r] + ts[(ny - (m >> 3) + 7) * 15 + (nx - (m & 7) + 7)];
+          if (a.shift) {
+            const int rid_m = __shfl(rid_tok, m);
+            if (rid_m != rid_n) sc += -100.0f;
+          }
+          S[mt][r] = sc;
+          mx = fmaxf(mx, sc);
         }
-        sc[m] = s;
-        mx = fmaxf(mx, s);
-        __builtin_amdgcn_sched_barrier(0);   // keep the next rows' LDS reads from being hoisted (register pressure)
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += expf(S[mt][r] - mx);
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      float D = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sc = S[mt][r], rl = fmaxf(sc, 0.f);
+          D = fmaf(dA[mt][r], expf(sc - mx) * inv, D);
+          t1 = fmaf(dA[mt][r], rl * rl, t1);
+        }
+      D += __shfl_xor(D, 32);
+      if (half == 0) g0 += D;      // (both halves hold the query's full sum)
+      g1 += t1;
+      st[0][n] = mx;
+      st[1][n] = inv;
+      st[2][n] = D;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sc = S[mt][r], rl = fmaxf(sc, 0.f), d = dA[mt][r];
+          S[mt][r] = w0 * (expf(sc - mx) * inv) * (d - D) + 2.0f * w1 * rl * d;   // dS^T
+        }
+      // dQ^T[e][n] = sum_m K[m][e] dS^T[m][n]
+      f32x16 O;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[r] = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float av = Ks[(mt * 32 + rowmap(r)) * WB_LD + l31];
+          O = __builtin_amdgcn_mfma_f32_32x32x2f32(av, S[mt][r], O, 0, 0, 0);
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the LDS reads from being hoisted in bulk)
+        }
+      float* __restrict__ op = a.dq + (long)img * a.dqkv_bs + (long)(h * 32 + 4 * half) * P + pixel(w, nt * 32 + l31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[(long)((r & 3) + 8 * (r >> 2)) * P] = O[r] * a.scale;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // the statistics are in LDS
+    // ---- "N" form: queries in the registers, the lane's column is a key; one half of the queries at a time ------
+    f32x16 OV[2], OK[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { OV[mt][r] = 0.f; OK[mt][r] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x16 S[2], dA[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[mt][r] = 0.f; dA[mt][r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          S[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[nt][s], kf[mt][s], S[mt], 0, 0, 0);
+          dA[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[nt][s], vf[mt][s], dA[mt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nt * 32 + rowmap(r);
+        const int ny = n >> 3, nx = n & 7;
+        const float mx = st[0][n], inv = st[1][n], D = st[2][n];
+        const int rid_n = a.shift ? __shfl(rid_tok, n) : 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int m = mt * 32 + l31;
+          float sc = S[mt][r] + ts[(ny - (m >> 3) + 7) * 15 + (nx - (m & 7) + 7)];
+          if (a.shift) {
+            const int rid_m = __shfl(rid_tok, m);
+            if (rid_m != rid_n) sc += -100.0f;
+          }
+          const float p0 = expf(sc - mx) * inv, rl = fmaxf(sc, 0.f), d = dA[mt][r];
+          S[mt][r] = w0 * p0 + w1 * rl * rl;                        // A[n][m]
+          dA[mt][r] = w0 * p0 * (d - D) + 2.0f * w1 * rl * d;        // dS[n][m]
+        }
       }
-    }
-    {
-      float g[32];
+      // dV^T[e][m] += sum_n dO[n][e] A[n][m];  dK^T[e][m] += sum_n (scale q)[n][e] dS[n][m];  dS also to LDS
 #pragma unroll
-      for (int e = 0; e < 32; ++e) g[e] = Gs[lane * WB_LD + e];
+      for (int r = 0; r < 16; ++r) {
+        const int n = nt * 32 + rowmap(r);
+        const float ga = Gs[n * WB_LD + l31], qa = Qs[n * WB_LD + l31];
 #pragma unroll
-      for (int m = 0; m < 64; ++m) {
-        float d = 0.f;
-        const float4* __restrict__ vr = reinterpret_cast<const float4*>(&Vs[m * WB_LD]);
-#pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-          const float4 vv = vr[e4];
-          d = fmaf(g[4 * e4 + 0], vv.x, d); d = fmaf(g[4 * e4 + 1], vv.y, d);
-          d = fmaf(g[4 * e4 + 2], vv.z, d); d = fmaf(g[4 * e4 + 3], vv.w, d);
+        for (int mt = 0; mt < 2; ++mt) {
+          OV[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, S[mt][r], OV[mt], 0, 0, 0);
+          OK[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, dA[mt][r], OK[mt], 0, 0, 0);
+          T[n * WB_TLD + mt * 32 + l31] = dA[mt][r];
         }
-        da[m] = d;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int m = 0; m < 64; ++m) sum += expf(sc[m] - mx);
-    const float inv = 1.0f / sum;
-    float D = 0.f, t1 = 0.f;
-#pragma unroll
-    for (int m = 0; m < 64; ++m) {
-      const float p0 = expf(sc[m] - mx) * inv, r = fmaxf(sc[m], 0.f);
-      D = fmaf(da[m], p0, D);
-      t1 = fmaf(da[m], r * r, t1);
-    }
-    g0 += D;
-    g1 += t1;
-    // (compiler-level barrier: the K rows are read again below rather than kept in registers since the score loop)
-    asm volatile("" ::: "memory");
-    float dq[32];
-#pragma unroll
-    for (int e = 0; e < 32; ++e) dq[e] = 0.f;
-#pragma unroll
-    for (int m = 0; m < 64; ++m) {
-      const float p0 = expf(sc[m] - mx) * inv, r = fmaxf(sc[m], 0.f);
-      T[lane * WB_TLD + m] = w0 * p0 + w1 * r * r;                      // A[n][m]
-      const float ds = w0 * p0 * (da[m] - D) + 2.0f * w1 * r * da[m];
-      da[m] = ds;
-      const float4* __restrict__ kr = reinterpret_cast<const float4*>(&Ks[m * WB_LD]);
-#pragma unroll
-      for (int e4 = 0; e4 < 8; ++e4) {
-        const float4 kv = kr[e4];
-        dq[4 * e4 + 0] = fmaf(ds, kv.x, dq[4 * e4 + 0]); dq[4 * e4 + 1] = fmaf(ds, kv.y, dq[4 * e4 + 1]);
-        dq[4 * e4 + 2] = fmaf(ds, kv.z, dq[4 * e4 + 2]); dq[4 * e4 + 3] = fmaf(ds, kv.w, dq[4 * e4 + 3]);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    {
-      float* __restrict__ dqp = a.dq + (long)img * a.dqkv_bs + (long)(h * 32) * P + pq;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) dqp[(long)e * P] = dq[e] * a.scale;
-    }
-    __syncthreads();
-    {   // lane = key token m: dv_m = sum_n A[n][m] dO_n
-      float dv[32];
+    for (int mt = 0; mt < 2; ++mt) {
+      float* __restrict__ vp = a.dv + (long)img * a.dqkv_bs + (long)(h * 32 + 4 * half) * P + pixel(w, mt * 32 + l31);
+      float* __restrict__ kp = a.dk + (long)img_k * a.dqkv_bs + (long)(hk * 32 + 4 * half) * P + pixel(wk, mt * 32 + l31);
 #pragma unroll
-      for (int e = 0; e < 32; ++e) dv[e] = 0.f;
-      for (int n = 0; n < 64; ++n) {
-        const float av = T[n * WB_TLD + lane];
-        const float4* __restrict__ gr = reinterpret_cast<const float4*>(&Gs[n * WB_LD]);
-#pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-          const float4 gv = gr[e4];
-          dv[4 * e4 + 0] = fmaf(av, gv.x, dv[4 * e4 + 0]); dv[4 * e4 + 1] = fmaf(av, gv.y, dv[4 * e4 + 1]);
-          dv[4 * e4 + 2] = fmaf(av, gv.z, dv[4 * e4 + 2]); dv[4 * e4 + 3] = fmaf(av, gv.w, dv[4 * e4 + 3]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        vp[(long)((r & 3) + 8 * (r >> 2)) * P] = OV[mt][r];
+        kp[(long)((r & 3) + 8 * (r >> 2)) * P] = OK[mt][r];
       }
-      float* __restrict__ dvp = a.dv + (long)img * a.dqkv_bs + (long)(h * 32) * P + pq;
-#pragma unroll
-      for (int e = 0; e < 32; ++e) dvp[(long)e * P] = dv[e];
     }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 64; ++m) T[lane * WB_TLD + m] = da[m];          // dS[n][m]
+    // ---- table gradient: the dS tile is in LDS, one lane per table entry ----------------------------------------------
     __syncthreads();
     // table entry i = (dy + 7) * 15 + (dx + 7) collects dS[n][m] of every pair with n - m = (dy, dx)
 #pragma unroll
@@ -711,24 +778,6 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
             sacc += T[(ny * 8 + nx) * WB_TLD + (ny - dy) * 8 + (nx - dx)];
         tacc[t4] += sacc;
       }
-    }
-    {   // lane = key token m: dk_m = sum_n dS[n][m] (scale q_n)
-      float dk[32];
-#pragma unroll
-      for (int e = 0; e < 32; ++e) dk[e] = 0.f;
-      for (int n = 0; n < 64; ++n) {
-        const float sv = T[n * WB_TLD + lane];
-        const float4* __restrict__ qr = reinterpret_cast<const float4*>(&Qs[n * WB_LD]);
-#pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-          const float4 qv = qr[e4];
-          dk[4 * e4 + 0] = fmaf(sv, qv.x, dk[4 * e4 + 0]); dk[4 * e4 + 1] = fmaf(sv, qv.y, dk[4 * e4 + 1]);
-          dk[4 * e4 + 2] = fmaf(sv, qv.z, dk[4 * e4 + 2]); dk[4 * e4 + 3] = fmaf(sv, qv.w, dk[4 * e4 + 3]);
-        }
-      }
-      float* __restrict__ dkp = a.dk + (long)img_k * a.dqkv_bs + (long)(hk * 32) * P + pk;
-#pragma unroll
-      for (int e = 0; e < 32; ++e) dkp[(long)e * P] = dk[e];
     }
   }
   __syncthreads();
