@@ -874,7 +874,7 @@ int guarded_t(F&& f) {
 // demand and kept until the process ends, so a step allocates nothing once the shapes have been seen.  All
 // training calls on one device share it and order their use through the stream: calls that overlap on one
 // device (two streams, two threads) race.
-enum { SC_PACK = 0, SC_PART_A = 1, SC_PART_B = 2, SC_SMALL = 3, SC_SLOTS = 4 };
+enum { SC_PACK = 0, SC_PART_A = 1, SC_PART_B = 2, SC_SMALL = 3, SC_SPLITK = 4, SC_SLOTS = 5 };
 void* train_scratch(int slot, size_t bytes) {
   static std::mutex mu;
   static DeviceBuffer pool[64][SC_SLOTS];
@@ -1065,6 +1065,9 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
     }
     JIRF_HIP_CHECK(hipGetLastError());
     g.M = M; g.Mpad = Mp; g.wt = wt; g.bias = bias_use;
+    // slabs of the split-K form (deep levels: long reductions over a handful of pixels)
+    g.splitk_ws = static_cast<float*>(train_scratch(SC_SPLITK, SPLITK_WS_FLOATS * sizeof(float)));
+    g.splitk_floats = SPLITK_WS_FLOATS;
     const long Pin = (long)Hin * Win;
     const long Pout = (g.epi == EP_SHUFFLE) ? 4L * g.P : g.P;
     g.x = tv(const_cast<float*>(x), dense(x_bs, Cin, Pin));
