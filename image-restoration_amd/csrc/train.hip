@@ -581,8 +581,12 @@ struct WinBwdArgs {
 };
 
 __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
-  __shared__ float Ks[64 * WB_LD], Gs[64 * WB_LD], Qs[64 * WB_LD];
-  __shared__ float T[64 * WB_TLD];
+  // (the K tile is only read in the "T" form and the dS tile only written after it: they share one region,
+  //  which brings a workgroup under 40 KB of LDS, four per CU)
+  __shared__ float KT[64 * WB_TLD];
+  __shared__ float Gs[64 * WB_LD], Qs[64 * WB_LD];
+  float* __restrict__ Ks = KT;
+  float* __restrict__ T = KT;
   __shared__ float ts[232];
   __shared__ float st[3][64];
   const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5, chunk = blockIdx.x, h = blockIdx.y;
