@@ -183,7 +183,10 @@ def train_step_bench(args, rank, local_rank, world, use_dist):
     cfg = default_config("AST")
     sd = make_state("AST", cfg, seed=1)
     B, S = args.train_batch, args.size
-    tr = AstTrainStep(cfg, sd, device=local_rank, lr=2e-4, use_grad_clip=True, coupled=True)
+    # stochastic depth at the reference's constructor default (drop_path_rate 0.1) unless --drop-path says otherwise;
+    # each rank draws its own keep decisions, like the reference's per-process generator
+    tr = AstTrainStep(cfg, sd, device=local_rank, lr=2e-4, use_grad_clip=True, coupled=True,
+                      drop_path_rate=args.drop_path, seed=rank)
     tr.broadcast_parameters()
     gt = torch.from_numpy(synthetic_images(B, S, S, seed=500 + rank, sigma=0)).cuda()
     lq = torch.from_numpy(synthetic_images(B, S, S, seed=500 + rank, sigma=25)).cuda()
@@ -219,7 +222,7 @@ def train_step_bench(args, rank, local_rank, world, use_dist):
                 "reference key layout, broadcast from rank 0)",
         "config": {"workload": f"AST (reference default constructor, token_mlp frfn, {tr.num_parameters()} parameters) "
                                f"optimisation step on {B} {S}x{S} crops per GPU: forward, smooth-L1, backward, gradient "
-                               "all-reduce (mean), clip 0.01, Adam; fp32; stochastic depth off",
+                               f"all-reduce (mean), clip 0.01, Adam; fp32; stochastic depth (DropPath) rate {tr.drop_path_rate:g}",
                    "batch_per_gpu": B, "height": S, "width": S,
                    "sharding": "one replica per rank, one all-reduce of the flat gradient buffer per step",
                    "gradient_floats": tr.n_flat},
@@ -308,6 +311,8 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="time the AST data-parallel optimisation step instead of the inference forward")
     ap.add_argument("--train-batch", type=int, default=2, help="crops per GPU per optimisation step (--train-step)")
+    ap.add_argument("--drop-path", type=float, default=None,
+                    help="stochastic depth rate of --train-step (default: the reference constructor's 0.1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

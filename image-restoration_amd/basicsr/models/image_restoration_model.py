@@ -69,7 +69,8 @@ class ImageCleanModel:
                                        lr=float(optim.get("lr", 1e-3)), betas=tuple(optim.get("betas", (0.9, 0.999))),
                                        eps=float(optim.get("eps", 1e-8)),
                                        use_grad_clip=bool(train_opt.get("use_grad_clip", False)),
-                                       loss_weight=float(pix.get("loss_weight", 1.0)))
+                                       loss_weight=float(pix.get("loss_weight", 1.0)),
+                                       seed=int(self.opt.get("manual_seed", 0) or 0))
         self.train_step.broadcast_parameters()
         self.log_dict = OrderedDict()
 

@@ -411,13 +411,17 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     }
   }
 }
-// y = a (+ b): the copies of the concatenations and the sums of gradients that meet at a shortcut
+// y = a (+ b): the copies of the concatenations and the sums of gradients that meet at a shortcut.
+// scale != null: y = a + scale[image] * b (a may be null): a branch under stochastic depth, whose output (and
+// output gradient) is multiplied per sample by 0 or 1 / keep_prob (DropPath, ast_arch.py:52-70).
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, long a_bs, const float* __restrict__ b2,
-                                                  long b_bs, float* __restrict__ y, long y_bs, long n_img) {
+                                                  long b_bs, const float* __restrict__ scale, float* __restrict__ y,
+                                                  long y_bs, long n_img) {
   const int b = blockIdx.y;
+  const float sc = scale ? scale[b] : 1.0f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_img; i += (long)gridDim.x * 256) {
-    float v = a[(long)b * a_bs + i];
-    if (b2) v += b2[(long)b * b_bs + i];
+    float v = a ? a[(long)b * a_bs + i] : 0.f;
+    if (b2) v = fmaf(sc, b2[(long)b * b_bs + i], v);
     y[(long)b * y_bs + i] = v;
   }
 }
@@ -1191,7 +1195,21 @@ int jirf_train_add(const float* a, long a_bs, const float* b, long b_bs, float* 
     const int gx = (int)std::min<long>(2048, (n_img + 255) / 256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(intern_label("train_add n%ld", n_img), 1.0 * B * (double)n_img, 4.0 * B * (double)n_img * (b ? 3 : 2), s);
-    hipLaunchKernelGGL(add_kernel, dim3(gx, B), dim3(256), 0, s, a, a_bs ? a_bs : n_img, b, b_bs ? b_bs : n_img, y,
+    hipLaunchKernelGGL(add_kernel, dim3(gx, B), dim3(256), 0, s, a, a_bs ? a_bs : n_img, b, b_bs ? b_bs : n_img,
+                       static_cast<const float*>(nullptr), y, y_bs ? y_bs : n_img, n_img);
+    JIRF_HIP_CHECK(hipGetLastError());
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_scale_add(const float* a, long a_bs, const float* b, long b_bs, const float* scale, float* y, long y_bs,
+                         int B, long n_img, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(b && scale && y && B > 0 && n_img > 0, JIRF_EINVAL, "train_scale_add: bad arguments");
+    const int gx = (int)std::min<long>(2048, (n_img + 255) / 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(intern_label("train_scale_add n%ld", n_img), 2.0 * B * (double)n_img, 4.0 * B * (double)n_img * (a ? 3 : 2), s);
+    hipLaunchKernelGGL(add_kernel, dim3(gx, B), dim3(256), 0, s, a, a_bs ? a_bs : n_img, b, b_bs ? b_bs : n_img, scale, y,
                        y_bs ? y_bs : n_img, n_img);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;

@@ -75,6 +75,7 @@ SIGNATURES = {
     "jirf_train_gelu": (_i, [_fp, _l, _fp, _l, _fp, _l, _i, _l, _i, _vp]),
     "jirf_train_gelu_bwd": (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _l, _fp, _l, _i, _l, _i, _vp]),
     "jirf_train_add": (_i, [_fp, _l, _fp, _l, _fp, _l, _i, _l, _vp]),
+    "jirf_train_scale_add": (_i, [_fp, _l, _fp, _l, _fp, _fp, _l, _i, _l, _vp]),
     "jirf_train_channel_sum": (_i, [_fp, _l, _fp, _i, _i, _l, _i, _vp]),
     "jirf_train_dwconv3x3": (_i, [_fp, _l, _fp, _fp, _fp, _l, _i, _i, _i, _i, _i, _vp]),
     "jirf_train_dwconv3x3_bwd_weight": (_i, [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _vp]),

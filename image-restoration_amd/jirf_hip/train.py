@@ -14,9 +14,10 @@ Parameters, gradients and the two Adam moments live in four flat fp32 buffers wi
 parameter starts on a 256-byte boundary); the data-parallel step averages the gradient buffer over the ranks
 with one all-reduce (`torch.distributed`, RCCL on GPUs) and nothing else is exchanged.
 
-Not reproduced: the stochastic depth of the reference in training mode (DropPath, ast_arch.py:52-70, rate 0.1
-by the constructor default) is a random per-sample mask on each branch; here `drop_path_masks` can supply such
-masks explicitly, and without them every branch is kept (rate 0).
+Stochastic depth (DropPath, ast_arch.py:52-70; rate 0.1 by the constructor default, per-block schedule
+:981-983) is applied as in the reference's training mode: each branch of each block is multiplied per sample
+by 0 or 1 / keep_prob.  The factors come from a seeded torch generator (the reference draws them from Jittor's
+generator, whose stream cannot be reproduced); `drop_scales` supplies them explicitly instead (tests).
 """
 from __future__ import annotations
 
@@ -91,7 +92,8 @@ class AstTrainStep:
 
     def __init__(self, cfg: dict, state: Dict[str, np.ndarray], device: int = 0, lr: float = 2e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, use_grad_clip: bool = True, max_norm: float = 0.01,
-                 loss_weight: float = 1.0, coupled: bool = True, adam_form: str = "jittor", process_group=None):
+                 loss_weight: float = 1.0, coupled: bool = True, adam_form: str = "jittor", process_group=None,
+                 drop_path_rate: Optional[float] = None, seed: int = 0):
         if cfg.get("token_mlp", "leff") != "frfn":
             raise NotImplementedError("AstTrainStep: only token_mlp='frfn' (the shipped AST configurations) is built")
         if not torch.cuda.is_available():
@@ -132,7 +134,11 @@ class AstTrainStep:
         self.v = torch.zeros_like(self.p)
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.load_state_dict(state)
-        self.drop_path_masks = None
+        # stochastic depth: the option's rate (constructor default 0.1, ast_arch.py:955) unless given here
+        self.drop_path_rate = float(cfg.get("drop_path_rate", 0.1) if drop_path_rate is None else drop_path_rate)
+        self.drop_scales: Optional[Dict[str, np.ndarray]] = None      # explicit factors per branch (tests)
+        self._gen = torch.Generator(device="cpu")
+        self._gen.manual_seed(int(seed))
         self.last_loss = None
 
     # ---- parameters --------------------------------------------------------------------------------------------
@@ -214,9 +220,44 @@ class AstTrainStep:
         check(self.L.jirf_train_add(_vp(a.ptr), a.bs, _vp(b.ptr if b else None), b.bs if b else 0, _vp(y.ptr), y.bs, B,
                                     n_img, self._s()))
 
+    def _draw_scales(self, B: int) -> None:
+        """Draws this step's DropPath factors (drop_path(), ast_arch.py:62-70: per sample 0 or 1 / keep_prob) for
+        every branch with a non-zero rate, in forward order, and moves them to the device in one copy."""
+        rows, keys = [], []
+        for bl in self._blocks():
+            for branch in (("attn", "mlp") if bl["att"] else ("mlp",)):
+                key = f"{bl['name']}.{branch}"
+                if self.drop_scales is not None:
+                    if key in self.drop_scales:
+                        f = torch.as_tensor(np.asarray(self.drop_scales[key], np.float32)).reshape(-1)
+                        if f.numel() != B:
+                            raise ValueError(f"drop_scales[{key}]: {f.numel()} factors for a batch of {B}")
+                        rows.append(f)
+                        keys.append(key)
+                elif bl["drop"] > 0.0:
+                    keep = 1.0 - bl["drop"]
+                    rows.append((torch.rand(B, generator=self._gen) < keep).to(torch.float32) / keep)
+                    keys.append(key)
+        self._scales = {}
+        if rows:
+            d = torch.stack(rows).to(self.device)
+            self._scales = {k: d[i] for i, k in enumerate(keys)}
+
+    def _branch_scale(self, bl, branch: str, B: int) -> Optional[torch.Tensor]:
+        """DropPath factors of one branch for this step ([B] on the device), or None when the branch is kept."""
+        return self._scales.get(f"{bl['name']}.{branch}")
+
+    def scale_add(self, a: Optional[V], b: V, scale: torch.Tensor, y: V, B, n_img):
+        check(self.L.jirf_train_scale_add(_vp(a.ptr if a else None), a.bs if a else 0, _vp(b.ptr), b.bs,
+                                          _vp(scale.data_ptr()), _vp(y.ptr), y.bs, B, n_img, self._s()))
+
     # ---- one TransformerBlock (ast_arch.py:768-842) -------------------------------------------------------------
     def _blocks(self):
         out = []
+        n_enc = sum(self.depths[:4])
+        enc = [float(v) for v in torch.linspace(0, self.drop_path_rate, n_enc)] if n_enc > 1 else [0.0] * n_enc
+        dec = enc[::-1]                                   # ast_arch.py:981-983
+        e = k = 0
         for li in range(9):
             for j in range(self.depths[li]):
                 Cn = self.E * MULT[li]
@@ -226,8 +267,18 @@ class AstTrainStep:
                 att = li >= 4
                 if att and win != 8:
                     raise NotImplementedError("AstTrainStep: only 8 x 8 windows are built")
+                if li < 4:
+                    rate, e = enc[e], e + 1
+                elif li == 4:
+                    rate = self.drop_path_rate
+                else:
+                    if k >= len(dec):                     # the reference's constructor fails the same way
+                        if self.drop_path_rate > 0.0:
+                            raise IndexError("list index out of range (drop-path schedule: more decoder than encoder blocks)")
+                        dec.append(0.0)
+                    rate, k = dec[k], k + 1
                 out.append(dict(name=f"{LAYERS[li]}.blocks.{j}", layer=li, C=Cn, hidden=int(Cn * self.mlp_ratio),
-                                heads=self.heads[li], att=att, shift=shift))
+                                heads=self.heads[li], att=att, shift=shift, drop=rate))
         return out
 
     def _block_fwd(self, bl, x: V, out: V, B, H, W):
@@ -248,8 +299,14 @@ class AstTrainStep:
                                                      _vp(self.P(a + ".w")), _vp(ao.ptr), ao.bs, B, Cn, H, W, bl["heads"],
                                                      bl["shift"], self.coupled, self._s()))
             x1 = self.buf(B, Cn, P)
-            self.conv(ao, self.P(a + ".proj.weight"), W_FWD, self.P(a + ".proj.bias"), x, x1, B, Cn, Cn, H, W, epi=EP_RESID)
-            sv.update(n1=n1, qkv=qkv, ao=ao, x1=x1)
+            sa = self._branch_scale(bl, "attn", B)
+            if sa is None:
+                self.conv(ao, self.P(a + ".proj.weight"), W_FWD, self.P(a + ".proj.bias"), x, x1, B, Cn, Cn, H, W, epi=EP_RESID)
+            else:                                          # x + drop_path(branch)
+                br = self.buf(B, Cn, P)
+                self.conv(ao, self.P(a + ".proj.weight"), W_FWD, self.P(a + ".proj.bias"), None, br, B, Cn, Cn, H, W)
+                self.scale_add(x, br, sa, x1, B, Cn * P)
+            sv.update(n1=n1, qkv=qkv, ao=ao, x1=x1, s_attn=sa)
             cur = x1
         m = n + ".mlp"
         cat = self.buf(B, Cn, P)                       # norm2(x), then its first C/4 channels replaced by the 3x3's output
@@ -267,19 +324,29 @@ class AstTrainStep:
                                           self._s()))
         gated = self.buf(B, h, P)
         self.gelu(predw, act1.chan(h, P), gated, B, h * P, 1)
-        self.conv(gated, self.P(m + ".linear2.0.weight"), W_FWD, self.P(m + ".linear2.0.bias"), cur, out, B, h, Cn, H, W,
-                  epi=EP_RESID)
-        sv.update(cur=cur, cat=cat, first=first, pre1=pre1, act1=act1, predw=predw, gated=gated)
+        sm = self._branch_scale(bl, "mlp", B)
+        if sm is None:
+            self.conv(gated, self.P(m + ".linear2.0.weight"), W_FWD, self.P(m + ".linear2.0.bias"), cur, out, B, h, Cn, H, W,
+                      epi=EP_RESID)
+        else:
+            br = self.buf(B, Cn, P)
+            self.conv(gated, self.P(m + ".linear2.0.weight"), W_FWD, self.P(m + ".linear2.0.bias"), None, br, B, h, Cn, H, W)
+            self.scale_add(cur, br, sm, out, B, Cn * P)
+        sv.update(cur=cur, cat=cat, first=first, pre1=pre1, act1=act1, predw=predw, gated=gated, s_mlp=sm)
         return sv
 
     def _block_bwd(self, bl, sv, dout: V, B, H, W) -> V:
         n, Cn, h, P = bl["name"], bl["C"], bl["hidden"], H * W
         dc = Cn // 4
         m = n + ".mlp"
-        # linear2
-        self.conv_dw(dout, sv["gated"], self.G(m + ".linear2.0.weight"), self.G(m + ".linear2.0.bias"), B, Cn, h, H, W, H, W)
+        # linear2 (under stochastic depth the branch sees the output gradient times its per-sample factor)
+        dbr = dout
+        if sv.get("s_mlp") is not None:
+            dbr = self.buf(B, Cn, P)
+            self.scale_add(None, dout, sv["s_mlp"], dbr, B, Cn * P)
+        self.conv_dw(dbr, sv["gated"], self.G(m + ".linear2.0.weight"), self.G(m + ".linear2.0.bias"), B, Cn, h, H, W, H, W)
         dgated = self.buf(B, h, P)
-        self.conv(dout, self.P(m + ".linear2.0.weight"), W_BWD_DATA, None, None, dgated, B, Cn, h, H, W)
+        self.conv(dbr, self.P(m + ".linear2.0.weight"), W_BWD_DATA, None, None, dgated, B, Cn, h, H, W)
         # gate and depthwise 3x3
         dact1 = self.buf(B, 2 * h, P)
         dpredw = self.buf(B, h, P)
@@ -305,9 +372,13 @@ class AstTrainStep:
         if not bl["att"]:
             return dcur
         a = n + ".attn"
-        self.conv_dw(dcur, sv["ao"], self.G(a + ".proj.weight"), self.G(a + ".proj.bias"), B, Cn, Cn, H, W, H, W)
+        dbr = dcur
+        if sv.get("s_attn") is not None:
+            dbr = self.buf(B, Cn, P)
+            self.scale_add(None, dcur, sv["s_attn"], dbr, B, Cn * P)
+        self.conv_dw(dbr, sv["ao"], self.G(a + ".proj.weight"), self.G(a + ".proj.bias"), B, Cn, Cn, H, W, H, W)
         dao = self.buf(B, Cn, P)
-        self.conv(dcur, self.P(a + ".proj.weight"), W_BWD_DATA, None, None, dao, B, Cn, Cn, H, W)
+        self.conv(dbr, self.P(a + ".proj.weight"), W_BWD_DATA, None, None, dao, B, Cn, Cn, H, W)
         dqkv = self.buf(B, 3 * Cn, P)
         qkv = sv["qkv"]
         check(self.L.jirf_train_window_attention_bwd(
@@ -327,7 +398,8 @@ class AstTrainStep:
 
     # ---- the network (AST.execute ast_arch.py:1220-1256) -------------------------------------------------------------
     def forward_backward(self, lq: torch.Tensor, gt: torch.Tensor, backward: bool = True):
-        """Fills the gradient buffer with d loss / d parameters of this rank's batch and returns (loss, prediction)."""
+        """Fills the gradient buffer with d loss / d parameters of this rank's batch and returns (loss, prediction).
+        backward=False runs the forward alone, in evaluation mode (no stochastic depth)."""
         lq = lq.to(self.device, torch.float32).contiguous()
         gt = gt.to(self.device, torch.float32).contiguous()
         B, Cin, H, W = lq.shape
@@ -338,6 +410,10 @@ class AstTrainStep:
         Pl = [(H >> l) * (W >> l) for l in range(5)]
         Cl = [E << l for l in range(5)]
         blocks = self._blocks()
+        if backward:
+            self._draw_scales(B)
+        else:
+            self._scales = {}                             # forward only = evaluation mode: DropPath is the identity
         by_layer = [[b for b in blocks if b["layer"] == li] for li in range(9)]
         saved: Dict[str, dict] = {}
         xin = V(lq.data_ptr(), Cin * Pl[0], lq)

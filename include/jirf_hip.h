@@ -306,6 +306,11 @@ int jirf_train_gelu_bwd(const float* pre, long pre_bs, const float* x2, long x2_
 /* y = a (+ b, or NULL): concatenation copies and the sums of gradients that meet at a shortcut. */
 int jirf_train_add(const float* a, long a_bs, const float* b, long b_bs, float* y, long y_bs, int B, long n_img,
                    void* stream);
+/* y = a + scale[image] * b (a may be NULL: y = scale[image] * b); scale [B] is a device array.  A branch under
+ * stochastic depth (DropPath, ast_arch.py:52-70,837,840): its output, and in the backward its output gradient, is
+ * multiplied per sample by 0 or 1 / keep_prob. */
+int jirf_train_scale_add(const float* a, long a_bs, const float* b, long b_bs, const float* scale, float* y, long y_bs,
+                         int B, long n_img, void* stream);
 /* out [C] (+)= sum_{b,p} x[b][c][p] (the bias gradient of the transposed convolution). */
 int jirf_train_channel_sum(const float* x, long x_bs, float* out, int B, int C, long P, int accumulate, void* stream);
 /* Depthwise 3x3 (zero pad 1, ast_arch.py:458-466) on device weights w [C,1,3,3], bias [C] or NULL; flip != 0 reverses

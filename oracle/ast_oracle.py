@@ -181,8 +181,17 @@ def token_mlp(kind: str):
     raise Exception("FFN error!")
 
 
+def _drop_path(t: torch.Tensor, scales: Optional[dict], key: str) -> torch.Tensor:
+    """DropPath in training mode (:52-70): the branch times a per-sample factor, 0 or 1 / keep_prob.  The factors are
+    given (the reference draws them from Jittor's generator); None or a missing key = the branch is kept."""
+    if not scales or key not in scales:
+        return t
+    f = torch.as_tensor(scales[key], dtype=t.dtype).reshape((t.shape[0],) + (1,) * (t.ndim - 1))
+    return t * f
+
+
 def transformer_block(p: Params, pre: str, x: torch.Tensor, heads: int, win: int, shift: int,
-                      att: bool, tap: Tap = None, ffn=frfn) -> torch.Tensor:
+                      att: bool, tap: Tap = None, ffn=frfn, drop_scales: Optional[dict] = None) -> torch.Tensor:
     """TransformerBlock.execute (:768-842), `mask` argument None (as in every script)."""
     B, L, C = x.shape
     H = W = int(math.sqrt(L))
@@ -196,8 +205,9 @@ def transformer_block(p: Params, pre: str, x: torch.Tensor, heads: int, win: int
         t = window_reverse(a.reshape(-1, win, win, C), win, H, W)
         if shift > 0:
             t = torch.roll(t, shifts=(shift, shift), dims=(1, 2))
-        x = x + t.reshape(B, H * W, C)
-    x = x + ffn(p, pre + ".mlp", token_layernorm(x, p[pre + ".norm2.weight"], p[pre + ".norm2.bias"]))
+        x = x + _drop_path(t.reshape(B, H * W, C), drop_scales, pre + ".attn")
+    x = x + _drop_path(ffn(p, pre + ".mlp", token_layernorm(x, p[pre + ".norm2.weight"], p[pre + ".norm2.bias"])),
+                       drop_scales, pre + ".mlp")
     if tap:
         tap(pre + ".out", x.clone())
     return x
@@ -213,8 +223,31 @@ def _to_tokens(t: torch.Tensor) -> torch.Tensor:
     return t.flatten(2).transpose(1, 2)
 
 
-def ast_forward(state: dict, x: torch.Tensor, cfg: Optional[dict] = None, tap: Tap = None) -> torch.Tensor:
-    """AST.execute (:1220-1256)."""
+def drop_path_rates(cfg: dict) -> dict:
+    """Per-block drop-path rate (:981-983, :1010-1190): linspace(0, rate, number of encoder blocks) over the four
+    encoder layers, `rate` for the bottleneck, the encoder list reversed over the four decoder layers."""
+    d = cfg["depths"]
+    rate = float(cfg.get("drop_path_rate", 0.1))
+    n_enc = sum(d[:4])
+    enc = [float(v) for v in torch.linspace(0, rate, n_enc)] if n_enc > 1 else [0.0] * n_enc
+    dec = enc[::-1]
+    out, e, k = {}, 0, 0
+    for li in range(9):
+        for j in range(d[li]):
+            if li < 4:
+                r = enc[e]; e += 1
+            elif li == 4:
+                r = rate
+            else:
+                r = dec[k]; k += 1
+            out[f"{LAYERS[li]}.blocks.{j}"] = r
+    return out
+
+
+def ast_forward(state: dict, x: torch.Tensor, cfg: Optional[dict] = None, tap: Tap = None,
+                drop_scales: Optional[dict] = None) -> torch.Tensor:
+    """AST.execute (:1220-1256).  drop_scales: training-mode DropPath factors per branch ("<block>.attn" /
+    "<block>.mlp" -> [B]); None = evaluation mode."""
     cfg = cfg or default_config()
     p = as_params(state)
     x = x.float()
@@ -225,7 +258,7 @@ def ast_forward(state: dict, x: torch.Tensor, cfg: Optional[dict] = None, tap: T
         name, _, div, depth, heads, att = plan[i]
         for j in range(depth):
             win, shift = block_window(cfg, div, j)
-            t = transformer_block(p, f"{name}.blocks.{j}", t, heads, win, shift, att, tap, ffn)
+            t = transformer_block(p, f"{name}.blocks.{j}", t, heads, win, shift, att, tap, ffn, drop_scales)
         return t
 
     def down(i, t):

@@ -152,6 +152,15 @@ def test_gelu_and_gate_backward():
     # y = a + b on slices, and the channel sum
     call("jirf_train_add", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(yf), 0, B, Cn * P, stream())
     assert rel_err(yf.cpu().numpy(), both[:, :Cn] + both[:, Cn:]) < 1e-6
+    # y = a + s[image] * b (the drop-path residual; one fused multiply-add) and y = s[image] * b (bit-exact)
+    sc = np.array([0.0, 1.0 / 0.9], np.float32)
+    scd = dev(sc)
+    call("jirf_train_scale_add", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(scd), ptr(yf), 0, B,
+         Cn * P, stream())
+    assert rel_err(yf.cpu().numpy(), both[:, :Cn] + sc[:, None, None] * both[:, Cn:]) < 2e-7
+    assert np.array_equal(yf.cpu().numpy()[0], both[0, :Cn])
+    call("jirf_train_scale_add", None, 0, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(scd), ptr(yf), 0, B, Cn * P, stream())
+    assert np.array_equal(yf.cpu().numpy(), sc[:, None, None] * both[:, Cn:])
     cs = torch.zeros(Cn, device="cuda")
     call("jirf_train_channel_sum", C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(cs), B, Cn, P, 0, stream())
     assert rel_err(cs.cpu().numpy(), both[:, Cn:].astype(np.float64).sum(axis=(0, 2))) < 1e-5

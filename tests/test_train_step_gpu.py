@@ -6,7 +6,9 @@ own autograd cannot run here) and a NumPy restatement of Jittor's clip_grad_norm
    (the literal batched call: the window / head pairing of K runs over the whole batch), within 1e-3 of
    autograd's, and the fraction of parameters covered (all of them);
  * the weights after iteration 1 (no clip) and iteration 2 (clip 0.01) against the oracle's;
- * the training forward equals the inference forward of the same weights.
+ * the training forward equals the inference forward of the same weights (stochastic depth off);
+ * stochastic depth (DropPath): the per-block rates, the gradients under given per-sample factors against
+   autograd over the oracle with the same factors, and the statistics of the drawn factors.
 """
 import numpy as np
 import pytest
@@ -23,7 +25,9 @@ REL = 1e-3
 
 def _cfg():
     cfg = so.default_config()
-    cfg["depths"] = [1, 1, 1, 1, 2, 1, 1, 1, 2]      # shifted blocks at the bottleneck and at full resolution
+    # shifted blocks at the bottleneck and at full resolution; as many decoder blocks as encoder blocks (the
+    # reference's drop-path schedule indexes the reversed encoder list by decoder block, ast_arch.py:983-1190)
+    cfg["depths"] = [2, 1, 1, 1, 2, 1, 1, 1, 2]
     return cfg
 
 
@@ -40,9 +44,9 @@ def _data(B, S, seed):
     return lq, gt
 
 
-def _oracle_grads(sd, lq, gt, cfg):
+def _oracle_grads(sd, lq, gt, cfg, drop_scales=None):
     params = {k: torch.from_numpy(np.ascontiguousarray(v)).requires_grad_(True) for k, v in sd.items()}
-    pred = so.ast_forward(params, torch.from_numpy(lq), cfg)
+    pred = so.ast_forward(params, torch.from_numpy(lq), cfg, drop_scales=drop_scales)
     loss = F.smooth_l1_loss(pred, torch.from_numpy(gt), reduction="none").mean()      # losses.py:12-14
     loss.backward()
     return float(loss.detach()), pred.detach().numpy(), {k: v.grad.numpy() for k, v in params.items()}
@@ -69,7 +73,7 @@ def test_gradients_and_two_steps_against_the_oracle():
     lq, gt = _data(2, 128, 3)
     loss_ref, pred_ref, g_ref = _oracle_grads(sd, lq, gt, cfg)
 
-    tr = AstTrainStep(cfg, sd, lr=2e-4, coupled=True)
+    tr = AstTrainStep(cfg, sd, lr=2e-4, coupled=True, drop_path_rate=0.0)
     loss, pred = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt))
     assert max_abs(pred.cpu().numpy(), pred_ref) < 1e-3
     assert abs(loss - loss_ref) < 1e-5 * abs(loss_ref)
@@ -119,7 +123,7 @@ def test_gradients_at_the_benchmark_configuration():
     sd = _state(cfg, 1)
     lq, gt = _data(2, 256, 13)
     loss_ref, pred_ref, g_ref = _oracle_grads(sd, lq, gt, cfg)
-    tr = AstTrainStep(cfg, sd, coupled=True)
+    tr = AstTrainStep(cfg, sd, coupled=True, drop_path_rate=0.0)
     loss, pred = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt))
     assert max_abs(pred.cpu().numpy(), pred_ref) < 1e-3
     assert abs(loss - loss_ref) < 1e-5 * abs(loss_ref)
@@ -141,11 +145,76 @@ def test_training_forward_equals_the_inference_forward():
     net.load_state_dict(sd)
     net.cuda().eval()
     for coupled, mode in ((False, "per_image"), (True, "coupled")):
-        tr = AstTrainStep(cfg, sd, coupled=coupled)
+        tr = AstTrainStep(cfg, sd, coupled=coupled, drop_path_rate=0.0)
         _, pred = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt), backward=False)
         net.batch_mode = mode
         y = net(torch.from_numpy(lq).cuda())
         assert max_abs(pred.cpu().numpy(), y.cpu().numpy()) < 2e-5, mode
+
+
+def test_stochastic_depth_against_the_oracle_with_the_same_factors():
+    """DropPath in training mode (reference ast_arch.py:52-70, :837, :840, rates :981-983).  The reference draws
+    the per-sample keep decisions from Jittor's generator; here they are given, to the GPU step and to the oracle
+    alike, at a rate (0.5) that drops many branches: per-block rates, prediction, loss and every gradient."""
+    from jirf_hip.train import AstTrainStep
+    cfg = dict(_cfg(), drop_path_rate=0.5)
+    sd = _state(cfg, 17)
+    lq, gt = _data(2, 128, 19)
+    tr = AstTrainStep(cfg, sd, coupled=True)
+    rates = {b["name"]: b["drop"] for b in tr._blocks()}
+    want_rates = so.drop_path_rates(cfg)
+    assert rates.keys() == want_rates.keys() and all(abs(rates[k] - want_rates[k]) < 1e-7 for k in rates)
+    assert rates["encoderlayer_0.blocks.0"] == 0.0 and rates["conv.blocks.1"] == 0.5 and rates["decoderlayer_0.blocks.0"] == 0.5
+    rng = np.random.default_rng(23)
+    scales = {}
+    for name, r in want_rates.items():
+        for branch in (("attn", "mlp") if not name.startswith(("encoderlayer", "dowsample")) else ("mlp",)):
+            if r > 0:
+                scales[f"{name}.{branch}"] = ((rng.random(2) < 1 - r) / (1 - r)).astype(np.float32)
+    dropped = sum(int((v == 0).sum()) for v in scales.values())
+    assert dropped >= 3                                       # the case exercises dropped branches
+    loss_ref, pred_ref, g_ref = _oracle_grads(sd, lq, gt, cfg, drop_scales=scales)
+    tr.drop_scales = scales
+    loss, pred = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt))
+    assert max_abs(pred.cpu().numpy(), pred_ref) < 1e-3
+    assert abs(loss - loss_ref) < 1e-5 * abs(loss_ref)
+    g = tr.grad_dict()
+    worst = max(((float(np.abs(g[k] - w).max()) / max(float(np.abs(w).max()), 1e-12), k) for k, w in g_ref.items()))
+    print(f"[AST training step, DropPath] {dropped} of {sum(v.size for v in scales.values())} branch samples dropped; "
+          f"worst relative gradient error {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < REL
+    # and it differs from the step without stochastic depth (the factors are applied)
+    loss0, _, _ = _oracle_grads(sd, lq, gt, cfg)
+    assert abs(loss0 - loss_ref) > 1e-4 * abs(loss_ref)
+
+
+def test_stochastic_depth_draws():
+    """Drawn factors: 0 or 1 / keep_prob per sample, about keep_prob of them kept, the same stream for the same
+    seed, none drawn at rate 0, and evaluation (`backward=False` on the inference class) is unaffected."""
+    from jirf_hip.train import AstTrainStep
+    cfg = _cfg()
+    sd = _state(cfg, 3)
+    a = AstTrainStep(cfg, sd, seed=5)                        # rate 0.1: the constructor default of the reference
+    assert a.drop_path_rate == pytest.approx(0.1)
+    kept = total = 0
+    for _ in range(40):
+        a._draw_scales(8)
+        for key, f in a._scales.items():
+            r = {b["name"]: b["drop"] for b in a._blocks()}[key.rsplit(".", 1)[0]]
+            vals = f.cpu().numpy()
+            assert np.all((vals == 0) | (np.abs(vals - 1 / (1 - r)) < 1e-6))
+            if abs(r - 0.1) < 1e-9:
+                kept += int((vals > 0).sum())
+                total += vals.size
+    assert total > 500 and abs(kept / total - 0.9) < 0.05
+    b, c = AstTrainStep(cfg, sd, seed=5), AstTrainStep(cfg, sd, seed=6)
+    a2 = AstTrainStep(cfg, sd, seed=5)
+    a2._draw_scales(8); b._draw_scales(8); c._draw_scales(8)
+    assert all(torch.equal(a2._scales[k], b._scales[k]) for k in b._scales)
+    assert any(not torch.equal(c._scales[k], b._scales[k]) for k in b._scales)
+    z = AstTrainStep(cfg, sd, drop_path_rate=0.0)
+    z._draw_scales(8)
+    assert z._scales == {}
 
 
 def test_gradient_mean_over_two_shards_equals_the_batch_gradient():
@@ -156,7 +225,7 @@ def test_gradient_mean_over_two_shards_equals_the_batch_gradient():
     cfg = _cfg()
     sd = _state(cfg, 4)
     lq, gt = _data(2, 128, 21)
-    tr = AstTrainStep(cfg, sd, coupled=False)
+    tr = AstTrainStep(cfg, sd, coupled=False, drop_path_rate=0.0)
     loss, _ = tr.forward_backward(torch.from_numpy(lq), torch.from_numpy(gt))
     g_all = tr.g.clone()
     parts, losses = [], []
@@ -176,7 +245,7 @@ def test_a_few_steps_reduce_the_loss():
     cfg = _cfg()
     sd = _state(cfg, 2)
     lq, gt = _data(1, 128, 9)
-    tr = AstTrainStep(cfg, sd, lr=1e-3, use_grad_clip=False)
+    tr = AstTrainStep(cfg, sd, lr=1e-3, use_grad_clip=False, drop_path_rate=0.0)
     losses = [tr.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt)) for _ in range(6)]
     print("[AST training step] losses on one fixed batch:", " ".join(f"{x:.5f}" for x in losses))
     assert losses[-1] < losses[0]
@@ -200,7 +269,7 @@ def test_model_wrapper_runs_the_step_from_the_option_tree(tmp_path):
                      "optim_g": {"type": "Adam", "lr": 2e-4, "betas": [0.9, 0.999]},
                      "pixel_opt": {"type": "L1Loss", "loss_weight": 1, "reduction": "mean"}}}
     model = create_model(opt)
-    ref = AstTrainStep(cfg, sd, lr=2e-4, use_grad_clip=True)
+    ref = AstTrainStep(cfg, sd, lr=2e-4, use_grad_clip=True, seed=100)     # the option's manual_seed
     for it in (1, 2):
         lq, gt = _data(2, 128, 30 + it)
         model.feed_train_data({"lq": torch.from_numpy(lq), "gt": torch.from_numpy(gt)})
