@@ -186,7 +186,7 @@ def train_step_bench(args, rank, local_rank, world, use_dist):
     # stochastic depth at the reference's constructor default (drop_path_rate 0.1) unless --drop-path says otherwise;
     # each rank draws its own keep decisions, like the reference's per-process generator
     tr = AstTrainStep(cfg, sd, device=local_rank, lr=2e-4, use_grad_clip=True, coupled=True,
-                      drop_path_rate=args.drop_path, seed=rank)
+                      drop_path_rate=args.drop_path, seed=rank, use_graph=not args.no_graph)
     tr.broadcast_parameters()
     gt = torch.from_numpy(synthetic_images(B, S, S, seed=500 + rank, sigma=0)).cuda()
     lq = torch.from_numpy(synthetic_images(B, S, S, seed=500 + rank, sigma=25)).cuda()
@@ -197,15 +197,19 @@ def train_step_bench(args, rank, local_rank, world, use_dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    losses = []
+    # the loss of every step stays on the device until the run is over (the reference's loss is a lazy Jittor
+    # variable, evaluated when the logger prints it): nothing in the loop waits for the GPU
+    losses_dev = []
     for _ in range(args.warmup):
-        losses.append(tr.optimize_parameters(lq, gt))
+        losses_dev.append(tr.optimize_parameters(lq, gt, sync_loss=False).clone())
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(tr.optimize_parameters(lq, gt))
+        losses_dev.append(tr.optimize_parameters(lq, gt, sync_loss=False).clone())
+    host_elapsed = time.perf_counter() - t0               # the host's share: queueing the steps
     sync_all()
     elapsed = time.perf_counter() - t0
+    losses = [float(t.item()) for t in losses_dev]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -227,6 +231,7 @@ def train_step_bench(args, rank, local_rank, world, use_dist):
                    "sharding": "one replica per rank, one all-reduce of the flat gradient buffer per step",
                    "gradient_floats": tr.n_flat},
         "loss_first": round(losses[0], 6), "loss_last": round(losses[-1], 6),
+        "host_queueing_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
     }
     if use_dist and world > 1:
         # the exchange on its own: the same all-reduce, timed outside the step
@@ -311,6 +316,8 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="time the AST data-parallel optimisation step instead of the inference forward")
     ap.add_argument("--train-batch", type=int, default=2, help="crops per GPU per optimisation step (--train-step)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="--train-step: queue every kernel of a step from the host instead of replaying the captured step")
     ap.add_argument("--drop-path", type=float, default=None,
                     help="stochastic depth rate of --train-step (default: the reference constructor's 0.1)")
     args = ap.parse_args()

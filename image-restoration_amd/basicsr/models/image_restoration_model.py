@@ -81,13 +81,13 @@ class ImageCleanModel:
         self.feed_data(data)
 
     def optimize_parameters(self, current_iter):     # :235-276
-        self.train_step.optimize_parameters(self.lq, self.gt, current_iter)
+        self.train_step.optimize_parameters(self.lq, self.gt, current_iter, sync_loss=False)
         self.output = self.train_step.output
-        self.log_dict = OrderedDict(l_pix=self.train_step.log_loss)
+        self.log_dict = OrderedDict(l_pix=self.train_step.log_loss)     # still on the device: read when it is logged
         self._net_is_stale = True
 
     def get_current_log(self):
-        return self.log_dict
+        return OrderedDict((k, float(v.item()) if isinstance(v, torch.Tensor) else v) for k, v in self.log_dict.items())
 
     def sync_network(self):
         """Copies the trained weights into net_g (validation and save_network read them from there)."""

@@ -9,7 +9,9 @@
 // reduction is two-stage with a fixed order (no atomics), so a step is reproducible.
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <mutex>
+#include <vector>
 
 #include "runtime.h"
 
@@ -64,11 +66,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   const double t = block_sum_d(acc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-__global__ void sum_parts_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < n; ++i) t += part[i];
-    out[0] = t;
+// out = scale * sum(part[0..n)): one wave, lane l adds parts l, l + 64, ..., then a butterfly of fixed shape.
+__global__ __launch_bounds__(64) void sum_parts_kernel(const double* __restrict__ part, int n, double* __restrict__ out,
+                                                       double scale, double* __restrict__ out2) {
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) t += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (threadIdx.x == 0) {
+    out[0] = t * scale;
+    if (out2) out2[0] = t * scale;
   }
 }
 
@@ -138,28 +145,47 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restri
   const int lr = lane / NT_LPR, lc = (lane % NT_LPR) * 4;   // loader: NT_RPI rows x NT_LPR float4 per instruction
   // the chunk's global loads: issued one chunk ahead, so that they are in flight during the MFMA phase
   float4 va[NT_U], vb[NT_U];
+  int tap_off[NT_U], tap_ky[NT_U], tap_kx[NT_U];   // CONV: the gathered rows' input plane and tap (loop-invariant)
+  if constexpr (CONV) {
+    const int taps = cg.ks * cg.ks;
+#pragma unroll
+    for (int u = 0; u < NT_U; ++u) {
+      const int k = min(k0 + lr + NT_RPI * u, K - 1);
+      const int ch = k / taps, t = k - ch * taps;
+      tap_ky[u] = t / cg.ks;
+      tap_kx[u] = t - tap_ky[u] * cg.ks;
+      tap_off[u] = ch * cg.Hin * cg.Win;
+    }
+  }
   auto fetch = [&](long c) {
     const int b = (int)(c / chunks_img);
     const int p0 = (int)(c - (long)b * chunks_img) * NT_PX;
     const float* __restrict__ dyb = dy + (long)b * dy_bs;
     const float* __restrict__ xb = x + (long)b * x_bs;
+    const int pa = min(p0 + lc, P - 4);   // clamped address; the tail is zeroed when the chunk is staged
+    int gy[4], gx[4];                     // CONV: the four pixels' input coordinates at tap (0, 0)
+    if constexpr (CONV) {
+      const int oy0 = pa / cg.Wout, ox0 = pa - oy0 * cg.Wout;   // one division per chunk; Wout >= 4
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool wrap = ox0 + j >= cg.Wout;
+        gy[j] = (oy0 + (wrap ? 1 : 0)) * cg.stride - cg.pad;
+        gx[j] = (ox0 + j - (wrap ? cg.Wout : 0)) * cg.stride - cg.pad;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < NT_U; ++u) {
       const int row = lr + NT_RPI * u;
-      const int pa = min(p0 + lc, P - 4);   // clamped address; the tail is zeroed when the chunk is staged
       va[u] = *reinterpret_cast<const float4*>(dyb + (long)min(m0 + row, M - 1) * P + pa);
       if constexpr (!CONV) {
         vb[u] = *reinterpret_cast<const float4*>(xb + (long)min(k0 + row, K - 1) * P + pa);
       } else {
-        const int k = min(k0 + row, K - 1), taps = cg.ks * cg.ks;
-        const int ch = k / taps, t = k - ch * taps, ky = t / cg.ks, kx = t - ky * cg.ks;
-        const float* __restrict__ plane = xb + (long)ch * cg.Hin * cg.Win;
+        const float* __restrict__ plane = xb + tap_off[u];
         float g4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int p = pa + j, oy = p / cg.Wout, ox = p - oy * cg.Wout;
-          const int sy = oy * cg.stride - cg.pad + ky, sx = ox * cg.stride - cg.pad + kx;
-          const bool in = sy >= 0 && sy < cg.Hin && sx >= 0 && sx < cg.Win;
+          const int sy = gy[j] + tap_ky[u], sx = gx[j] + tap_kx[u];
+          const bool in = (unsigned)sy < (unsigned)cg.Hin && (unsigned)sx < (unsigned)cg.Win;
           const float v = plane[in ? sy * cg.Win + sx : 0];
           g4[j] = in ? v : 0.f;
         }
@@ -236,30 +262,225 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const float* __restri
   }
 }
 
-// out[e] (+)= sum over slabs of part[slab][e].  A workgroup owns 16 consecutive outputs; its 16 thread groups add
-// every 16th slab each and the 16 sums meet in LDS in group order (a fixed order: reproducible).
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, long n, int slabs,
-                                                           float* __restrict__ out, int accumulate) {
-  __shared__ float red[16][16];
+// The same contraction with the operand chunks shared by the workgroup's four waves.  The kernel above loads
+// 2 x 64 rows per 64 x 64 tile and wave (16 flop per byte moved from the caches, which is what bounds it); here a
+// workgroup owns a (WM TI 32) x (WK TJ 32) tile of dW, stages the [rows][16 px] chunks of both operands once in LDS
+// (double-buffered, one barrier per chunk, the next chunk's global loads in flight during the MFMA phase) and wave
+// (wm, wk) accumulates its (TI 32) x (TJ 32) part: 32 flop per byte at 128 x 128.  Rows past M / K are loaded from
+// the last valid row (their products land in outputs that are never written), so the loop has no row masks; a
+// ragged last chunk of the plane is zero-filled.  Each output element belongs to one wave: the slab's tile is
+// written from the accumulators directly; db (wk == 0, k-tile 0) likewise.
+template <bool CONV, int WM, int WK, int TI, int TJ>
+__global__ __launch_bounds__(256, 2) void dw_shared_kernel(const float* __restrict__ dy, long dy_bs,
+                                                           const float* __restrict__ x, long x_bs,
+                                                           float* __restrict__ part, double* __restrict__ dbpart,
+                                                           int B, int M, int K, int P, int chunks_per_slab,
+                                                           ConvGeom cg) {
+  static_assert(WM * WK == 4, "four waves");
+  constexpr int TM = WM * TI * 32, TK = WK * TJ * 32;
+  constexpr int UA = (TM + 63) / 64, UB = (TK + 63) / 64;   // float4 per thread and chunk (64 rows per instruction)
+  __shared__ float lds[2][(TM + TK) * NT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WK, wk = wave % WK;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TK, slab = blockIdx.z;
+  const int chunks_img = (P + NT_PX - 1) / NT_PX;
+  const long chunks = (long)chunks_img * B;
+  const long c_lo = (long)slab * chunks_per_slab, c_hi = min(chunks, c_lo + chunks_per_slab);
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  double dbacc = 0.0;   // wk == 0: row m0 + wm TI 32 + lane
+  const int lr = tid >> 2, lc = (tid & 3) * 4;
+  float4 va[UA], vb[UB];
+  int tap_off[UB], tap_ky[UB], tap_kx[UB];   // CONV: the gathered rows' input plane and tap (loop-invariant)
+  if constexpr (CONV) {
+    const int taps = cg.ks * cg.ks;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int k = min(k0 + lr + 64 * u, K - 1);
+      const int ch = k / taps, t = k - ch * taps;
+      tap_ky[u] = t / cg.ks;
+      tap_kx[u] = t - tap_ky[u] * cg.ks;
+      tap_off[u] = ch * cg.Hin * cg.Win;
+    }
+  }
+  auto fetch = [&](long c) {
+    const int b = (int)(c / chunks_img);
+    const int p0 = (int)(c - (long)b * chunks_img) * NT_PX;
+    const float* __restrict__ dyb = dy + (long)b * dy_bs;
+    const float* __restrict__ xb = x + (long)b * x_bs;
+    const int pa = min(p0 + lc, P - 4);
+    int gy[4], gx[4];                     // CONV: the four pixels' input coordinates at tap (0, 0)
+    if constexpr (CONV) {
+      const int oy0 = pa / cg.Wout, ox0 = pa - oy0 * cg.Wout;   // one division per chunk; Wout >= 4
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool wrap = ox0 + j >= cg.Wout;
+        gy[j] = (oy0 + (wrap ? 1 : 0)) * cg.stride - cg.pad;
+        gx[j] = (ox0 + j - (wrap ? cg.Wout : 0)) * cg.stride - cg.pad;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int row = lr + 64 * u;
+      if (TM % 64 == 0 || row < TM) va[u] = *reinterpret_cast<const float4*>(dyb + (long)min(m0 + row, M - 1) * P + pa);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int row = lr + 64 * u;
+      if (TK % 64 == 0 || row < TK) {
+        if constexpr (!CONV) {
+          vb[u] = *reinterpret_cast<const float4*>(xb + (long)min(k0 + row, K - 1) * P + pa);
+        } else {
+          const float* __restrict__ plane = xb + tap_off[u];
+          float g4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int sy = gy[j] + tap_ky[u], sx = gx[j] + tap_kx[u];
+            const bool in = (unsigned)sy < (unsigned)cg.Hin && (unsigned)sx < (unsigned)cg.Win;
+            const float v = plane[in ? sy * cg.Win + sx : 0];
+            g4[j] = in ? v : 0.f;
+          }
+          vb[u] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        }
+      }
+    }
+  };
+  if (c_lo < c_hi) fetch(c_lo);
+  for (long c = c_lo; c < c_hi; ++c) {
+    float* __restrict__ A = lds[(c - c_lo) & 1];
+    float* __restrict__ Bm = A + TM * NT_LD;
+    const int p0 = (int)(c - (c / chunks_img) * chunks_img) * NT_PX;
+    const bool pin = p0 + lc < P;   // P % 4 == 0: a float4 is inside the plane or outside it as a whole
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int row = lr + 64 * u;
+      if (TM % 64 == 0 || row < TM) {
+        float* d = A + row * NT_LD + lc;
+        d[0] = pin ? va[u].x : 0.f, d[1] = pin ? va[u].y : 0.f, d[2] = pin ? va[u].z : 0.f, d[3] = pin ? va[u].w : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int row = lr + 64 * u;
+      if (TK % 64 == 0 || row < TK) {
+        float* d = Bm + row * NT_LD + lc;
+        d[0] = pin ? vb[u].x : 0.f, d[1] = pin ? vb[u].y : 0.f, d[2] = pin ? vb[u].z : 0.f, d[3] = pin ? vb[u].w : 0.f;
+      }
+    }
+    if (c + 1 < c_hi) fetch(c + 1);
+    // one barrier per chunk: the other buffer was last read in the previous trip's MFMA phase, which every wave
+    // has left before it arrives here, so the next trip may overwrite it
+    __syncthreads();
+    if (wk == 0 && blockIdx.y == 0 && lane < TI * 32) {
+      const float* __restrict__ ar = A + (wm * TI * 32 + lane) * NT_LD;
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT_PX; ++j) t += ar[j];
+      dbacc += t;
+    }
+    const float* __restrict__ Aw = A + (wm * TI * 32 + l31) * NT_LD + half;
+    const float* __restrict__ Bw = Bm + (wk * TJ * 32 + l31) * NT_LD + half;
+#pragma unroll
+    for (int q = 0; q < NT_PX / 2; ++q) {
+      float af[TI], bf[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) af[i] = Aw[i * 32 * NT_LD + 2 * q];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bf[j] = Bw[j * 32 * NT_LD + 2 * q];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* __restrict__ out = part + (long)slab * M * K;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = k0 + (wk * TJ + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M && col < K) out[(long)row * K + col] = acc[i][j][r];
+      }
+    }
+  if (wk == 0 && blockIdx.y == 0 && dbpart && lane < TI * 32) {
+    const int row = m0 + wm * TI * 32 + lane;
+    if (row < M) dbpart[(long)slab * M + row] = dbacc;
+  }
+}
+
+// out[e] (+)= sum over slabs of part[slab][e], and in the same launch db[c] (+)= sum over slabs of dbpart[slab][c]
+// (workgroups w_blocks and up).  vec: a thread owns four consecutive outputs and adds the slabs in order (large n,
+// few slabs: coalesced 16-byte reads).  Otherwise a workgroup owns 16 consecutive outputs; its 16 thread groups add
+// every 16th slab each and the 16 sums meet in LDS in group order.  Either way the order is fixed: reproducible.
+__global__ __launch_bounds__(256) void reduce_dw_kernel(const float* __restrict__ part, long n, int slabs,
+                                                        float* __restrict__ out, const double* __restrict__ dbpart,
+                                                        int M, float* __restrict__ db, unsigned w_blocks, int vec,
+                                                        int accumulate) {
+  __shared__ double red[16][16];
   const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  if (blockIdx.x >= w_blocks) {
+    const int c = (int)(blockIdx.x - w_blocks) * 16 + col;
+    double t = 0.0;
+    if (c < M)
+      for (int s = grp; s < slabs; s += 16) t += dbpart[(long)s * M + c];
+    red[grp][col] = t;
+    __syncthreads();
+    if (grp == 0 && c < M) {
+      double v = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += red[g][col];
+      db[c] = accumulate ? db[c] + (float)v : (float)v;
+    }
+    return;
+  }
+  if (vec) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= n) return;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < slabs; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long)s * n + e);
+      t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out + e);
+    if (accumulate) {
+      const float4 v = *o;
+      t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+    }
+    *o = t;
+    return;
+  }
+  float* redf = reinterpret_cast<float*>(&red[0][0]);
   const long e = (long)blockIdx.x * 16 + col;
   float t = 0.f;
   if (e < n)
     for (int s = grp; s < slabs; s += 16) t += part[(long)s * n + e];
-  red[grp][col] = t;
+  redf[grp * 16 + col] = t;
   __syncthreads();
   if (grp == 0 && e < n) {
     float v = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) v += red[g][col];
+    for (int g = 0; g < 16; ++g) v += redf[g * 16 + col];
     out[e] = accumulate ? out[e] + v : v;
   }
 }
 // out[c] (+)= sum over slots of part[slot][c], one workgroup per column: thread t adds slots t, t + 256, ... and
-// the 256 sums meet in a tree of fixed shape, so the result does not depend on timing.
-__global__ __launch_bounds__(256) void reduce_cols_d_kernel(const double* __restrict__ part, int n, int slots,
-                                                            float* __restrict__ out, int accumulate) {
+// the 256 sums meet in a tree of fixed shape, so the result does not depend on timing.  blockIdx.y = 1 does the
+// same for a second (part, out) pair of the same shape.
+__global__ __launch_bounds__(256) void reduce_cols_d_kernel(const double* __restrict__ part0, float* __restrict__ out0,
+                                                            const double* __restrict__ part1, float* __restrict__ out1,
+                                                            int n, int slots, int accumulate) {
   __shared__ double red[256];
+  const double* __restrict__ part = blockIdx.y ? part1 : part0;
+  float* __restrict__ out = blockIdx.y ? out1 : out0;
   const int c = blockIdx.x;
   double t = 0.0;
   for (int s = threadIdx.x; s < slots; s += 256) t += part[(long)s * n + c];
@@ -425,6 +646,29 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, l
     y[(long)b * y_bs + i] = v;
   }
 }
+// Stochastic depth: out[row][b] = 0 with probability rate[row], else 1 / (1 - rate[row]) (drop_path(), reference
+// ast_arch.py:62-70).  Counter-based: the uniform variate of (row, b) at draw number counter[0] is a hash of
+// (seed, counter, row, b), so a sequence depends on the seed alone, not on how the launches are issued.  One
+// workgroup; it advances the counter when every thread has read it.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void drop_scales_kernel(float* __restrict__ out, const float* __restrict__ rate, int rows,
+                                                          int B, unsigned long long seed, unsigned long long* counter) {
+  const unsigned long long draw = counter[0];
+  __syncthreads();
+  for (int e = threadIdx.x; e < rows * B; e += 256) {
+    const int row = e / B;
+    const unsigned long long h = mix64(mix64(seed ^ (draw * 0xD1342543DE82EF95ull)) + (unsigned long long)e);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);   // 24 bits: [0, 1)
+    const float keep = 1.0f - rate[row];
+    out[e] = u < keep ? 1.0f / keep : 0.f;
+  }
+  if (threadIdx.x == 0) counter[0] = draw + 1;
+}
 // out[c] (+)= sum_{b,p} x[b][c][p] (the bias gradient of the transposed convolution): one workgroup per channel
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ out,
                                                           int B, long P, int accumulate) {
@@ -547,6 +791,61 @@ __global__ __launch_bounds__(256) void pack_train_kernel(const float* __restrict
 __global__ void expand_bias4_kernel(const float* __restrict__ b, float* __restrict__ out, int M) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < M) out[e] = b[e >> 2];
+}
+
+// All the packed forms of a step in one launch.  An item is one (weight, kind) pair; its packed matrix is cut into
+// 64 x 64 tiles of wt[k][o], one workgroup each (block0 = the item's first workgroup; the item's last workgroup
+// also expands the bias of a transposed convolution behind the matrix).  The tile goes through LDS so that both
+// sides are read and written in runs: the source is walked with its contiguous index fastest (kind 0: k, the
+// others: o), the packed matrix with o fastest.
+struct PackItem {
+  const float* w;
+  const float* bias;   // kind 2 only (or null): expanded to [4 Cout] at wt + Kp * Mp
+  float* wt;
+  int kind, M, Cin, taps, K, Kp, Mp;
+  unsigned block0, tiles_o;
+};
+__device__ __forceinline__ float pack_source(const PackItem& it, int k, int o) {
+  if (k >= it.K || o >= it.M) return 0.f;
+  const int tap = k / it.Cin, c = k - tap * it.Cin;
+  if (it.kind == 0) return it.w[((long)o * it.Cin + c) * it.taps + tap];
+  if (it.kind == 1) return it.w[((long)c * it.M + o) * it.taps + (it.taps - 1 - tap)];
+  if (it.kind == 2) return it.w[(long)k * it.M + o];
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int ci = o >> 2, ky = ((o >> 1) & 1) + 1 - 2 * dy, kx = (o & 1) + 1 - 2 * dx;
+  return (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) ? it.w[(((long)c * (it.M >> 2) + ci) * 4 + ky) * 4 + kx] : 0.f;
+}
+__global__ __launch_bounds__(256) void pack_plan_kernel(const PackItem* __restrict__ items, int n_items) {
+  __shared__ float tile[64][65];
+  __shared__ PackItem it;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_items - 1;   // the last item whose block0 <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].block0 <= blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
+    it = items[lo];
+  }
+  __syncthreads();
+  const unsigned t = blockIdx.x - it.block0;
+  const int k0 = (int)(t / it.tiles_o) * 64, o0 = (int)(t % it.tiles_o) * 64;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int fast = e & 63, slow = e >> 6;
+    const int kk = it.kind == 0 ? fast : slow, oo = it.kind == 0 ? slow : fast;
+    tile[kk][oo] = pack_source(it, k0 + kk, o0 + oo);
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int oo = e & 63, kk = e >> 6;
+    if (k0 + kk < it.Kp && o0 + oo < it.Mp) it.wt[(long)(k0 + kk) * it.Mp + o0 + oo] = tile[kk][oo];
+  }
+  if (it.bias && t + 1 == it.tiles_o * (unsigned)((it.Kp + 63) / 64))
+    for (int e = threadIdx.x; e < it.M; e += 256) it.wt[(long)it.Kp * it.Mp + e] = it.bias[e >> 2];
 }
 
 // ---- sparse window attention, backward (ast_arch.py:275-318; forward kernel: win_attn.hip) ------------------
@@ -900,31 +1199,94 @@ void* train_scratch(int slot, size_t bytes) {
 
 inline long dense(long bs, long c, long p) { return bs ? bs : c * p; }
 
+// Geometry of the packed form of one (weight, kind) pair: the GEMM's M, K, taps and the padded matrix.
+struct PackGeom {
+  int kind, M, K, taps, Kp, Mp;
+  long floats() const { return (long)Kp * Mp + Mp; }   // the matrix and room for an expanded bias
+};
+PackGeom pack_geom(int w_kind, int Cin, int Cout, int ks) {
+  PackGeom g{};
+  g.kind = w_kind == JIRF_W_FWD ? 0 : w_kind == JIRF_W_BWD_DATA ? 1 : w_kind == JIRF_W_DECONV ? 2 : 4;
+  g.taps = w_kind == JIRF_W_DECONV ? 1 : w_kind == JIRF_W_DOWN_BWD_DATA ? 9 : ks * ks;
+  g.M = (w_kind == JIRF_W_DECONV || w_kind == JIRF_W_DOWN_BWD_DATA) ? 4 * Cout : Cout;
+  g.K = g.taps * Cin;
+  g.Mp = (g.M + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+  g.Kp = (g.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  return g;
+}
+struct PackPlan {
+  int device = 0, n = 0;
+  unsigned blocks = 0;
+  DeviceBuffer items;
+  double bytes = 0.0;
+};
+
 // Per-kernel device time of the training operators (HIP events around every launch), for the calling thread.
 thread_local KernelClock g_train_clock;
 
-void conv_dw_launch(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, float* db, int B, int M, int K,
-                    int P, const ConvGeom* cg, int accumulate, hipStream_t s) {
-  const int tm = (M + NT_T - 1) / NT_T, tk = (K + NT_T - 1) / NT_T;
+template <bool CONV, int WM, int WK, int TI, int TJ>
+void dw_shared_launch(const float* dy, long dy_bs, const float* x, long x_bs, float*& part, double*& dbpart, bool want_db,
+                      int& slabs, int B, int M, int K, int P, const ConvGeom& cg, hipStream_t s) {
+  constexpr int TM = WM * TI * 32, TK = WK * TJ * 32;
+  const int tm = (M + TM - 1) / TM, tk = (K + TK - 1) / TK;
   const long chunks = (long)((P + NT_PX - 1) / NT_PX) * B;
-  // enough slabs to fill the chip (two workgroups per CU and then some), at least 16 chunks (4 per wave) each
-  int slabs = (int)std::max<long>(1, std::min<long>(chunks / 16, (2048 + tm * tk - 1) / (tm * tk)));
+  // three workgroups per CU and then some, at least 8 chunks each (the slabs cost a round trip of M K floats each)
+  slabs = (int)std::max<long>(1, std::min<long>(chunks / 8, (1024 + tm * tk - 1) / (tm * tk)));
   const int cps = (int)((chunks + slabs - 1) / slabs);
   slabs = (int)((chunks + cps - 1) / cps);
-  float* part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float)));
-  double* dbpart = db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double))) : nullptr;
+  part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float)));
+  dbpart = want_db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double))) : nullptr;
+  hipLaunchKernelGGL((dw_shared_kernel<CONV, WM, WK, TI, TJ>), dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs,
+                     part, dbpart, B, M, K, P, cps, cg);
+}
+
+void conv_dw_launch(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, float* db, int B, int M, int K,
+                    int P, const ConvGeom* cg, int accumulate, hipStream_t s) {
   Scope sc(intern_label("train_dw M%d K%d P%d", M, K, P), 2.0 * M * (double)K * P * B,
            4.0 * B * (double)P * (M + (cg ? K / (cg->ks * cg->ks) : K)), s);
-  if (cg)
-    hipLaunchKernelGGL(linear_dw_kernel<true>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart, B,
-                       M, K, P, cps, *cg);
-  else
-    hipLaunchKernelGGL(linear_dw_kernel<false>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart, B,
-                       M, K, P, cps, ConvGeom{});
+  float* part = nullptr;
+  double* dbpart = nullptr;
+  int slabs = 1;
+  const ConvGeom geom = cg ? *cg : ConvGeom{};
+#define JIRF_DW_SHARED(WM, WK, TI, TJ)                                                                             \
+  (cg ? dw_shared_launch<true, WM, WK, TI, TJ>(dy, dy_bs, x, x_bs, part, dbpart, db != nullptr, slabs, B, M, K, P, \
+                                               geom, s)                                                           \
+      : dw_shared_launch<false, WM, WK, TI, TJ>(dy, dy_bs, x, x_bs, part, dbpart, db != nullptr, slabs, B, M, K, P, \
+                                                geom, s))
+  if (M > 64 && K > 64) {
+    JIRF_DW_SHARED(2, 2, 2, 2);          // 128 x 128
+  } else if (M > 64 && K > 32) {
+    JIRF_DW_SHARED(4, 1, 2, 2);          // 256 x 64
+  } else if (M > 64) {
+    JIRF_DW_SHARED(4, 1, 2, 1);          // 256 x 32
+  } else if (K > 64 && M > 32) {
+    JIRF_DW_SHARED(1, 4, 2, 2);          // 64 x 256
+  } else if (K > 64) {
+    JIRF_DW_SHARED(1, 4, 1, 2);          // 32 x 256
+  } else {
+    // at most 64 x 64: every wave takes its own pixel chunks of the one tile row / column
+    const int tm = (M + NT_T - 1) / NT_T, tk = (K + NT_T - 1) / NT_T;
+    const long chunks = (long)((P + NT_PX - 1) / NT_PX) * B;
+    // enough slabs to fill the chip (two workgroups per CU and then some), at least 16 chunks (4 per wave) each
+    slabs = (int)std::max<long>(1, std::min<long>(chunks / 16, (2048 + tm * tk - 1) / (tm * tk)));
+    const int cps = (int)((chunks + slabs - 1) / slabs);
+    slabs = (int)((chunks + cps - 1) / cps);
+    part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float)));
+    dbpart = db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double))) : nullptr;
+    if (cg)
+      hipLaunchKernelGGL(linear_dw_kernel<true>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart,
+                         B, M, K, P, cps, geom);
+    else
+      hipLaunchKernelGGL(linear_dw_kernel<false>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart,
+                         B, M, K, P, cps, geom);
+  }
+#undef JIRF_DW_SHARED
   const long n = (long)M * K;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, n, slabs, dw,
-                     accumulate);
-  if (db) hipLaunchKernelGGL(reduce_cols_d_kernel, dim3(M), dim3(256), 0, s, dbpart, M, slabs, db, accumulate);
+  // one launch adds the slabs of dW and of db
+  const int vec = (n % 4 == 0 && n >= 32768 && slabs <= 64 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) ? 1 : 0;
+  const unsigned w_blocks = (unsigned)(vec ? (n / 4 + 255) / 256 : (n + 15) / 16);
+  hipLaunchKernelGGL(reduce_dw_kernel, dim3(w_blocks + (db ? (unsigned)((M + 15) / 16) : 0u)), dim3(256), 0, s, part, n,
+                     slabs, dw, dbpart, M, db, w_blocks, vec, accumulate);
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
@@ -964,9 +1326,9 @@ int jirf_train_kernel_times(const char** names_out, float* ms_out, double* flops
 }
 
 int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, long n, float loss_weight,
-                         double* loss_host, void* stream) {
+                         double* loss_dev, double* loss_host, void* stream) {
   return guarded_t([&] {
-    JIRF_REQUIRE(pred && target && n > 0 && loss_host, JIRF_EINVAL, "smooth_l1: bad arguments");
+    JIRF_REQUIRE(pred && target && n > 0 && (loss_dev || loss_host), JIRF_EINVAL, "smooth_l1: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<long>(1024, (n + 255) / 256);
     double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double)));
@@ -974,13 +1336,14 @@ int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, lo
       Scope sc("train_smooth_l1", 6.0 * n, 12.0 * n, s);
       hipLaunchKernelGGL(smooth_l1_kernel, dim3(blocks), dim3(256), 0, s, pred, target, grad, n,
                          loss_weight / (float)n, pd);
-      hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, pd + blocks);
+      hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, pd + blocks,
+                         (double)loss_weight / (double)n, loss_dev);
     }
     JIRF_HIP_CHECK(hipGetLastError());
-    double tot = 0.0;
-    JIRF_HIP_CHECK(hipMemcpyAsync(&tot, pd + blocks, sizeof(double), hipMemcpyDeviceToHost, s));
-    JIRF_HIP_CHECK(hipStreamSynchronize(s));
-    *loss_host = tot * (double)loss_weight / (double)n;
+    if (loss_host) {
+      JIRF_HIP_CHECK(hipMemcpyAsync(loss_host, pd + blocks, sizeof(double), hipMemcpyDeviceToHost, s));
+      JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    }
     return JIRF_OK;
   });
 }
@@ -994,7 +1357,8 @@ int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, 
     {
       Scope sc("train_grad_sumsq", 2.0 * n, 4.0 * n, s);
       hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, pd);
-      hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, out_dev ? out_dev : pd + blocks);
+      hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, s, pd, blocks, out_dev ? out_dev : pd + blocks, 1.0,
+                         static_cast<double*>(nullptr));
     }
     JIRF_HIP_CHECK(hipGetLastError());
     if (out_host) {
@@ -1025,6 +1389,8 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
                     int epi, void* stream) {
   return guarded_t([&] {
     JIRF_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, JIRF_EINVAL, "train_conv: bad arguments");
+    const bool packed = (w_kind & JIRF_W_PACKED) != 0;
+    w_kind &= ~JIRF_W_PACKED;
     JIRF_REQUIRE(w_kind == JIRF_W_FWD || w_kind == JIRF_W_BWD_DATA || w_kind == JIRF_W_DECONV ||
                      w_kind == JIRF_W_DOWN_BWD_DATA, JIRF_EINVAL, "train_conv: weight kind %d", w_kind);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1057,21 +1423,30 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
       }
     }
     (void)pk_cin;
-    const int Mp = (M + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD, Kp = (g.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
-    float* wt = static_cast<float*>(train_scratch(SC_PACK, ((size_t)Kp * Mp + Mp) * sizeof(float)));
-    const int kind = w_kind == JIRF_W_FWD ? 0 : w_kind == JIRF_W_BWD_DATA ? 1 : w_kind == JIRF_W_DECONV ? 2 : 4;
-    {
-      Scope sc(intern_label("train_pack_weights K%d M%d", g.K, M), 0.0, 4.0 * ((double)Kp * Mp + (double)g.K * M), s);
-      hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)(((long)Kp * Mp + 255) / 256)), dim3(256), 0, s, w, wt, kind, M,
-                         Cin, taps, g.K, Kp, Mp);
-    }
+    const PackGeom pg = pack_geom(w_kind, Cin, Cout, ks);
+    JIRF_REQUIRE(pg.M == M && pg.K == g.K && pg.taps == taps, JIRF_EINVAL, "train_conv: packed geometry");
+    const int Mp = pg.Mp, Kp = pg.Kp;
+    const float* wt = w;
     const float* bias_use = bias;
-    if (bias && w_kind == JIRF_W_DECONV) {
-      float* b4 = wt + (size_t)Kp * Mp;
-      hipLaunchKernelGGL(expand_bias4_kernel, dim3((M + 255) / 256), dim3(256), 0, s, bias, b4, M);
-      bias_use = b4;
+    if (packed) {
+      // w is the packed form already (jirf_train_pack_plan_run); the expanded bias of a transposed convolution
+      // sits behind the matrix
+      if (bias && w_kind == JIRF_W_DECONV) bias_use = w + (size_t)Kp * Mp;
+    } else {
+      float* wp = static_cast<float*>(train_scratch(SC_PACK, (size_t)pg.floats() * sizeof(float)));
+      {
+        Scope sc(intern_label("train_pack_weights K%d M%d", g.K, M), 0.0, 4.0 * ((double)Kp * Mp + (double)g.K * M), s);
+        hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)(((long)Kp * Mp + 255) / 256)), dim3(256), 0, s, w, wp,
+                           pg.kind, M, Cin, taps, g.K, Kp, Mp);
+      }
+      if (bias && w_kind == JIRF_W_DECONV) {
+        float* b4 = wp + (size_t)Kp * Mp;
+        hipLaunchKernelGGL(expand_bias4_kernel, dim3((M + 255) / 256), dim3(256), 0, s, bias, b4, M);
+        bias_use = b4;
+      }
+      JIRF_HIP_CHECK(hipGetLastError());
+      wt = wp;
     }
-    JIRF_HIP_CHECK(hipGetLastError());
     g.M = M; g.Mpad = Mp; g.wt = wt; g.bias = bias_use;
     // slabs of the split-K form (deep levels: long reductions over a handful of pixels)
     g.splitk_ws = static_cast<float*>(train_scratch(SC_SPLITK, SPLITK_WS_FLOATS * sizeof(float)));
@@ -1088,13 +1463,72 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
   });
 }
 
+long jirf_train_packed_floats(int w_kind, int Cin, int Cout, int ks) {
+  if (Cin <= 0 || Cout <= 0 || ks < 1 || (w_kind != JIRF_W_FWD && w_kind != JIRF_W_BWD_DATA && w_kind != JIRF_W_DECONV &&
+                                           w_kind != JIRF_W_DOWN_BWD_DATA))
+    return -1;
+  return pack_geom(w_kind, Cin, Cout, ks).floats();
+}
+
+int jirf_train_pack_plan_create(int n, const float* const* w, const float* const* bias, float* const* wt,
+                                const int* w_kind, const int* Cin, const int* Cout, const int* ks, void** plan_out) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(n > 0 && w && wt && w_kind && Cin && Cout && ks && plan_out, JIRF_EINVAL, "pack_plan_create: bad arguments");
+    std::vector<PackItem> items((size_t)n);
+    unsigned blocks = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+      JIRF_REQUIRE(w[i] && wt[i] && jirf_train_packed_floats(w_kind[i], Cin[i], Cout[i], ks[i]) > 0, JIRF_EINVAL,
+                   "pack_plan_create: item %d", i);
+      const PackGeom g = pack_geom(w_kind[i], Cin[i], Cout[i], ks[i]);
+      PackItem& it = items[(size_t)i];
+      it.w = w[i];
+      it.bias = (bias && w_kind[i] == JIRF_W_DECONV) ? bias[i] : nullptr;
+      it.wt = wt[i];
+      it.kind = g.kind; it.M = g.M; it.Cin = Cin[i]; it.taps = g.taps; it.K = g.K; it.Kp = g.Kp; it.Mp = g.Mp;
+      it.block0 = blocks;
+      it.tiles_o = (unsigned)((g.Mp + 63) / 64);
+      blocks += it.tiles_o * (unsigned)((g.Kp + 63) / 64);
+      bytes += 4.0 * ((double)g.Kp * g.Mp + (double)g.K * g.M);
+    }
+    auto plan = std::make_unique<PackPlan>();
+    JIRF_HIP_CHECK(hipGetDevice(&plan->device));
+    plan->n = n;
+    plan->blocks = blocks;
+    plan->bytes = bytes;
+    plan->items.ensure(items.size() * sizeof(PackItem));
+    JIRF_HIP_CHECK(hipMemcpy(plan->items.p, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice));
+    *plan_out = plan.release();
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_pack_plan_run(void* plan, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(plan, JIRF_EINVAL, "pack_plan_run: null plan");
+    const PackPlan* pl = static_cast<const PackPlan*>(plan);
+    int dev = 0;
+    JIRF_HIP_CHECK(hipGetDevice(&dev));
+    JIRF_REQUIRE(dev == pl->device, JIRF_EINVAL, "pack_plan_run: the plan belongs to device %d, current device %d", pl->device, dev);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(intern_label("train_pack_plan n%d", pl->n), 0.0, pl->bytes, s);
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(pl->blocks), dim3(256), 0, s, static_cast<const PackItem*>(pl->items.p), pl->n);
+    JIRF_HIP_CHECK(hipGetLastError());
+    return JIRF_OK;
+  });
+}
+
+void jirf_train_pack_plan_destroy(void* plan) { delete static_cast<PackPlan*>(plan); }
+
 int jirf_train_conv_bwd_weight(const float* dy, long dy_bs, const float* x, long x_bs, float* dw, float* db, int B,
                                int M, int Cin, int Hout, int Wout, int Hin, int Win, int ks, int stride, int pad,
                                int accumulate, void* stream) {
   return guarded_t([&] {
     const int P = Hout * Wout;
-    JIRF_REQUIRE(dy && x && dw && B > 0 && M > 0 && Cin > 0 && P >= 16 && P % 16 == 0 && ks >= 1 && stride >= 1 && pad >= 0,
-                 JIRF_EINVAL, "conv_bwd_weight: bad arguments (the output plane must be a multiple of 16 pixels)");
+    JIRF_REQUIRE(dy && x && dw && B > 0 && M > 0 && Cin > 0 && P >= 16 && P % 16 == 0 && Wout >= 4 && ks >= 1 &&
+                     stride >= 1 && pad >= 0,
+                 JIRF_EINVAL,
+                 "conv_bwd_weight: bad arguments (the output plane must be a multiple of 16 pixels, at least 4 wide)");
     JIRF_REQUIRE((Hin + 2 * pad - ks) / stride + 1 == Hout && (Win + 2 * pad - ks) / stride + 1 == Wout, JIRF_EINVAL,
                  "conv_bwd_weight: geometry out %dx%d in %dx%d k%d s%d p%d", Hout, Wout, Hin, Win, ks, stride, pad);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1151,8 +1585,8 @@ int jirf_train_layernorm_bwd(const float* x, long x_bs, const float* dy, long dy
       hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(gx, B), dim3(256), 0, s, x, dense(x_bs, C, P), dy,
                          dense(dy_bs, C, P), w, add, dense(add_bs, C, P), dx, dense(dx_bs, C, P), pw, pb, C, P,
                          kind == 1 ? 1 : 0);
-    hipLaunchKernelGGL(reduce_cols_d_kernel, dim3(C), dim3(256), 0, s, pw, C, slots, dw, accumulate);
-    if (db && kind == 1) hipLaunchKernelGGL(reduce_cols_d_kernel, dim3(C), dim3(256), 0, s, pb, C, slots, db, accumulate);
+    hipLaunchKernelGGL(reduce_cols_d_kernel, dim3(C, (db && kind == 1) ? 2 : 1), dim3(256), 0, s, pw, dw, pb, db, C, slots,
+                       accumulate);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });
@@ -1211,6 +1645,17 @@ int jirf_train_scale_add(const float* a, long a_bs, const float* b, long b_bs, c
     Scope sc(intern_label("train_scale_add n%ld", n_img), 2.0 * B * (double)n_img, 4.0 * B * (double)n_img * (a ? 3 : 2), s);
     hipLaunchKernelGGL(add_kernel, dim3(gx, B), dim3(256), 0, s, a, a_bs ? a_bs : n_img, b, b_bs ? b_bs : n_img, scale, y,
                        y_bs ? y_bs : n_img, n_img);
+    JIRF_HIP_CHECK(hipGetLastError());
+    return JIRF_OK;
+  });
+}
+
+int jirf_train_drop_path_scales(float* out, const float* rate, int rows, int B, unsigned long long seed,
+                                unsigned long long* counter, void* stream) {
+  return guarded_t([&] {
+    JIRF_REQUIRE(out && rate && counter && rows > 0 && B > 0, JIRF_EINVAL, "drop_path_scales: bad arguments");
+    hipLaunchKernelGGL(drop_scales_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, rate, rows, B, seed,
+                       counter);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });

@@ -63,7 +63,7 @@ SIGNATURES = {
     "jirf_train_kernel_timing": (_i, [_i]),
     "jirf_train_kernel_times": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(_i), _i, C.POINTER(_i)]),
-    "jirf_train_smooth_l1": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, C.POINTER(C.c_double), _vp]),
+    "jirf_train_smooth_l1": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, _fp, C.POINTER(C.c_double), _vp]),
     "jirf_train_sumsq": (_i, [_fp, C.c_long, _vp, C.POINTER(C.c_double), _vp]),
     "jirf_train_adam_step": (_i, [_fp, _fp, _fp, _fp, C.c_long, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _i, _i, _vp]),
@@ -77,6 +77,12 @@ SIGNATURES = {
     "jirf_train_add": (_i, [_fp, _l, _fp, _l, _fp, _l, _i, _l, _vp]),
     "jirf_train_scale_add": (_i, [_fp, _l, _fp, _l, _fp, _fp, _l, _i, _l, _vp]),
     "jirf_train_channel_sum": (_i, [_fp, _l, _fp, _i, _i, _l, _i, _vp]),
+    "jirf_train_drop_path_scales": (_i, [_fp, _fp, _i, _i, C.c_ulonglong, _fp, _vp]),
+    "jirf_train_packed_floats": (_l, [_i, _i, _i, _i]),
+    "jirf_train_pack_plan_create": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i),
+                                        C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
+    "jirf_train_pack_plan_run": (_i, [_vp, _vp]),
+    "jirf_train_pack_plan_destroy": (None, [_vp]),
     "jirf_train_dwconv3x3": (_i, [_fp, _l, _fp, _fp, _fp, _l, _i, _i, _i, _i, _i, _vp]),
     "jirf_train_dwconv3x3_bwd_weight": (_i, [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "jirf_train_window_attention": (_i, [_fp, _l, _fp, _fp, _fp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),

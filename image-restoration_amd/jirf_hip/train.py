@@ -16,8 +16,9 @@ with one all-reduce (`torch.distributed`, RCCL on GPUs) and nothing else is exch
 
 Stochastic depth (DropPath, ast_arch.py:52-70; rate 0.1 by the constructor default, per-block schedule
 :981-983) is applied as in the reference's training mode: each branch of each block is multiplied per sample
-by 0 or 1 / keep_prob.  The factors come from a seeded torch generator (the reference draws them from Jittor's
-generator, whose stream cannot be reproduced); `drop_scales` supplies them explicitly instead (tests).
+by 0 or 1 / keep_prob.  The factors are drawn on the device from a counter-based generator keyed by `seed` (the
+reference draws them from Jittor's generator, whose stream cannot be reproduced); `drop_scales` supplies them
+explicitly instead (tests).
 """
 from __future__ import annotations
 
@@ -32,7 +33,7 @@ import torch
 import jirf_hip
 from jirf_hip import check, lib
 
-W_FWD, W_BWD_DATA, W_DECONV, W_DOWN_BWD = 0, 1, 2, 4
+W_FWD, W_BWD_DATA, W_DECONV, W_DOWN_BWD, W_PACKED = 0, 1, 2, 4, 8
 EP_STORE, EP_RESID, EP_GELU, EP_LEAKY = 0, 1, 6, 7
 
 LAYERS = ["encoderlayer_0", "encoderlayer_1", "encoderlayer_2", "encoderlayer_3", "conv",
@@ -53,7 +54,8 @@ class V:
 
 
 def _vp(a: Optional[int]):
-    return None if a is None else C.c_void_p(a)
+    """A device address for a c_void_p parameter (ctypes converts ints and None itself)."""
+    return a
 
 
 def average_flat_gradients(g: torch.Tensor, group=None) -> None:
@@ -77,14 +79,17 @@ def broadcast_flat_parameters(p: torch.Tensor, group=None, src: int = 0) -> None
         dist.broadcast(p, src=src, group=group)
 
 
-def reduce_loss(loss: float, device, group=None) -> float:
-    """reduce_loss_dict (basicsr/models/base_model.py:287-305): the logged loss is the mean over the ranks."""
+def reduce_loss(loss, device, group=None):
+    """reduce_loss_dict (basicsr/models/base_model.py:287-305): the logged loss is the mean over the ranks.  A float
+    gives a float; a device tensor gives a device tensor (nothing waits for the value)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return loss
-    t = torch.tensor([loss], dtype=torch.float64, device=device)
+    lazy = isinstance(loss, torch.Tensor)
+    t = loss.detach().clone().reshape(1) if lazy else torch.tensor([loss], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return float(t.item()) / dist.get_world_size(group)
+    t = t / dist.get_world_size(group)
+    return t[0] if lazy else float(t.item())
 
 
 class AstTrainStep:
@@ -93,7 +98,7 @@ class AstTrainStep:
     def __init__(self, cfg: dict, state: Dict[str, np.ndarray], device: int = 0, lr: float = 2e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, use_grad_clip: bool = True, max_norm: float = 0.01,
                  loss_weight: float = 1.0, coupled: bool = True, adam_form: str = "jittor", process_group=None,
-                 drop_path_rate: Optional[float] = None, seed: int = 0):
+                 drop_path_rate: Optional[float] = None, seed: int = 0, use_graph: bool = False):
         if cfg.get("token_mlp", "leff") != "frfn":
             raise NotImplementedError("AstTrainStep: only token_mlp='frfn' (the shipped AST configurations) is built")
         if not torch.cuda.is_available():
@@ -137,9 +142,50 @@ class AstTrainStep:
         # stochastic depth: the option's rate (constructor default 0.1, ast_arch.py:955) unless given here
         self.drop_path_rate = float(cfg.get("drop_path_rate", 0.1) if drop_path_rate is None else drop_path_rate)
         self.drop_scales: Optional[Dict[str, np.ndarray]] = None      # explicit factors per branch (tests)
-        self._gen = torch.Generator(device="cpu")
-        self._gen.manual_seed(int(seed))
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._draw_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._scale_B, self._scales, self._scales_drawn = -1, {}, {}
+        self._stream = None
+        # use_graph: optimize_parameters replays forward + backward as one captured hipGraph (from the second step on)
+        self.use_graph = bool(use_graph)
+        self._graph, self._graph_key, self._graph_in, self._graph_out = None, None, None, None
+        self._timing = False
         self.last_loss = None
+        self._loss_ring = torch.zeros(64, dtype=torch.float64, device=self.device)
+        self._loss_slot = -1
+        self.loss_tensor = None
+        # packed weights: (weight address, kind, Cin, Cout, ks) -> packed buffer; filled after the first full step
+        self._pack_items: "OrderedDict[tuple, Optional[int]]" = OrderedDict()
+        self._packed: Dict[tuple, int] = {}
+        self._plan = None
+        self._packed_buf = None
+
+    def __del__(self):
+        if getattr(self, "_plan", None) is not None:
+            self.L.jirf_train_pack_plan_destroy(self._plan)
+            self._plan = None
+
+    def _build_pack_plan(self) -> None:
+        """One launch per step writes every packed weight form (jirf_train_pack_plan_*), instead of one small
+        kernel inside each convolution call.  The pairs are the ones the first step used."""
+        keys = list(self._pack_items)
+        n = len(keys)
+        sizes = [int(self.L.jirf_train_packed_floats(k[1], k[2], k[3], k[4])) for k in keys]
+        if n == 0 or min(sizes) <= 0:
+            raise RuntimeError("pack plan: bad weight geometry")
+        offs = np.concatenate([[0], np.cumsum([(s + 63) // 64 * 64 for s in sizes])])
+        self._packed_buf = torch.empty(int(offs[-1]), dtype=torch.float32, device=self.device)
+        base = self._packed_buf.data_ptr()
+        wt = [base + 4 * int(o) for o in offs[:-1]]
+        arr_p = (C.c_void_p * n)
+        arr_i = (C.c_int * n)
+        plan = C.c_void_p()
+        check(self.L.jirf_train_pack_plan_create(
+            n, arr_p(*[k[0] for k in keys]), arr_p(*[self._pack_items[k] for k in keys]), arr_p(*wt),
+            arr_i(*[k[1] for k in keys]), arr_i(*[k[2] for k in keys]), arr_i(*[k[3] for k in keys]),
+            arr_i(*[k[4] for k in keys]), C.byref(plan)))
+        self._plan = plan
+        self._packed = {k: p for k, p in zip(keys, wt)}
 
     # ---- parameters --------------------------------------------------------------------------------------------
     def load_state_dict(self, state: Dict[str, np.ndarray]) -> None:
@@ -181,7 +227,8 @@ class AstTrainStep:
 
     # ---- thin wrappers over the C ABI ------------------------------------------------------------------------------
     def _s(self):
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # looked up once per forward_backward (a captured step runs on the capture stream)
+        return self._stream if self._stream is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def buf(self, B: int, Cn: int, P: int) -> V:
         t = torch.empty(B * Cn * P, dtype=torch.float32, device=self.device)
@@ -189,6 +236,14 @@ class AstTrainStep:
 
     def conv(self, x: V, w: int, kind: int, bias: Optional[int], r: Optional[V], y: V, B, Cin, Cout, Hin, Win, ks=1,
              stride=1, pad=0, epi=EP_STORE):
+        # the packed form of (weight, kind) comes from the step's pack plan once the first step has listed the pairs
+        key = (w, kind, Cin, Cout, ks)
+        if self._plan is not None:
+            wt = self._packed.get(key)
+            if wt is not None:
+                w, kind = wt, kind | W_PACKED
+        else:
+            self._pack_items.setdefault(key, bias if kind == W_DECONV else None)
         check(self.L.jirf_train_conv(_vp(x.ptr), x.bs, _vp(w), kind, _vp(bias), _vp(r.ptr if r else None),
                                      r.bs if r else 0, _vp(y.ptr), y.bs, B, Cin, Cout, Hin, Win, ks, stride, pad, epi,
                                      self._s()))
@@ -220,28 +275,37 @@ class AstTrainStep:
         check(self.L.jirf_train_add(_vp(a.ptr), a.bs, _vp(b.ptr if b else None), b.bs if b else 0, _vp(y.ptr), y.bs, B,
                                     n_img, self._s()))
 
-    def _draw_scales(self, B: int) -> None:
-        """Draws this step's DropPath factors (drop_path(), ast_arch.py:62-70: per sample 0 or 1 / keep_prob) for
-        every branch with a non-zero rate, in forward order, and moves them to the device in one copy."""
-        rows, keys = [], []
-        for bl in self._blocks():
-            for branch in (("attn", "mlp") if bl["att"] else ("mlp",)):
-                key = f"{bl['name']}.{branch}"
-                if self.drop_scales is not None:
-                    if key in self.drop_scales:
-                        f = torch.as_tensor(np.asarray(self.drop_scales[key], np.float32)).reshape(-1)
-                        if f.numel() != B:
-                            raise ValueError(f"drop_scales[{key}]: {f.numel()} factors for a batch of {B}")
-                        rows.append(f)
-                        keys.append(key)
-                elif bl["drop"] > 0.0:
-                    keep = 1.0 - bl["drop"]
-                    rows.append((torch.rand(B, generator=self._gen) < keep).to(torch.float32) / keep)
-                    keys.append(key)
-        self._scales = {}
-        if rows:
-            d = torch.stack(rows).to(self.device)
+    def _draw_scales(self, B: int, launch: bool = True) -> None:
+        """This step's DropPath factors (drop_path(), ast_arch.py:62-70: per sample 0 or 1 / keep_prob) for every
+        branch with a non-zero rate, drawn on the device into a buffer that keeps its address (a captured step reads
+        the same buffer at every replay), or taken from `drop_scales` when that is set."""
+        if self.drop_scales is not None:
+            rows, keys = [], []
+            for key, f in self.drop_scales.items():
+                f = torch.as_tensor(np.asarray(f, np.float32)).reshape(-1)
+                if f.numel() != B:
+                    raise ValueError(f"drop_scales[{key}]: {f.numel()} factors for a batch of {B}")
+                rows.append(f)
+                keys.append(key)
+            d = torch.stack(rows).to(self.device) if rows else None
             self._scales = {k: d[i] for i, k in enumerate(keys)}
+            return
+        if self._scale_B != B:
+            keys, rates = [], []
+            for bl in self._blocks():
+                for branch in (("attn", "mlp") if bl["att"] else ("mlp",)):
+                    if bl["drop"] > 0.0:
+                        keys.append(f"{bl['name']}.{branch}")
+                        rates.append(bl["drop"])
+            self._scale_B = B
+            self._rate_dev = torch.tensor(rates, dtype=torch.float32, device=self.device)
+            self._scale_dev = torch.zeros(max(len(keys), 1), B, dtype=torch.float32, device=self.device)
+            self._scales_drawn = {k: self._scale_dev[i] for i, k in enumerate(keys)}
+        if self._scales_drawn and launch:
+            check(self.L.jirf_train_drop_path_scales(self._scale_dev.data_ptr(), self._rate_dev.data_ptr(),
+                                                     len(self._scales_drawn), B, self.seed, self._draw_counter.data_ptr(),
+                                                     self._s()))
+        self._scales = self._scales_drawn
 
     def _branch_scale(self, bl, branch: str, B: int) -> Optional[torch.Tensor]:
         """DropPath factors of one branch for this step ([B] on the device), or None when the branch is kept."""
@@ -397,11 +461,57 @@ class AstTrainStep:
         return dx
 
     # ---- the network (AST.execute ast_arch.py:1220-1256) -------------------------------------------------------------
-    def forward_backward(self, lq: torch.Tensor, gt: torch.Tensor, backward: bool = True):
+    def forward_backward(self, lq: torch.Tensor, gt: torch.Tensor, backward: bool = True, sync_loss: bool = True):
         """Fills the gradient buffer with d loss / d parameters of this rank's batch and returns (loss, prediction).
-        backward=False runs the forward alone, in evaluation mode (no stochastic depth)."""
+        backward=False runs the forward alone, in evaluation mode (no stochastic depth).  sync_loss=False returns
+        the loss as a 0-d float64 device tensor (valid for the next 64 steps) instead of waiting for it."""
         lq = lq.to(self.device, torch.float32).contiguous()
         gt = gt.to(self.device, torch.float32).contiguous()
+        self._stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        try:
+            loss_t, pred_t = self._forward_backward(lq, gt, backward, draw=True)
+        finally:
+            self._stream = None
+        return (float(loss_t.item()) if sync_loss else loss_t), pred_t
+
+    def _captured_forward_backward(self, lq: torch.Tensor, gt: torch.Tensor):
+        """forward_backward(backward=True) as one hipGraph launch.  The step is a fixed sequence of several hundred
+        kernels on fixed buffers, and queueing them one by one costs the host about as long as the GPU needs to run
+        them; captured once per input shape (after the eager steps that size the scratch buffers and list the packed
+        weights), it is replayed with the inputs copied into the captured step's buffers and the DropPath factors
+        drawn into theirs.  Returns (loss tensor, prediction) of the captured step's buffers."""
+        lq = lq.to(self.device, torch.float32)
+        gt = gt.to(self.device, torch.float32)
+        key = tuple(lq.shape)
+        if self._graph is None or self._graph_key != key:
+            self._graph = None
+            self._graph_in = (torch.empty_like(lq, memory_format=torch.contiguous_format),
+                              torch.empty_like(gt, memory_format=torch.contiguous_format))
+            self._draw_scales(key[0], launch=False)       # allocates the factor buffers outside the capture
+            self._graph_loss = torch.zeros((), dtype=torch.float64, device=self.device)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                try:
+                    self.g.zero_()
+                    out = self._forward_backward(self._graph_in[0], self._graph_in[1], True, draw=False,
+                                                 loss_out=self._graph_loss)
+                finally:
+                    self._stream = None
+            self._graph, self._graph_key, self._graph_out = graph, key, out
+        self._graph_in[0].copy_(lq)
+        self._graph_in[1].copy_(gt)
+        self._draw_scales(key[0])
+        self._graph.replay()
+        loss_t, pred_t = self._graph_out
+        self._loss_slot = (self._loss_slot + 1) % self._loss_ring.numel()
+        self._loss_ring[self._loss_slot].copy_(loss_t)    # the captured step always writes the same slot
+        self.loss_tensor = self._loss_ring[self._loss_slot]
+        return self.loss_tensor, pred_t
+
+    def _forward_backward(self, lq: torch.Tensor, gt: torch.Tensor, backward: bool, draw: bool,
+                          loss_out: Optional[torch.Tensor] = None):
         B, Cin, H, W = lq.shape
         if Cin != self.dd_in or H != W or H % 128 != 0:
             raise ValueError(f"AST takes square inputs with side % 128 == 0 and {self.dd_in} channels, got {tuple(lq.shape)}")
@@ -410,10 +520,12 @@ class AstTrainStep:
         Pl = [(H >> l) * (W >> l) for l in range(5)]
         Cl = [E << l for l in range(5)]
         blocks = self._blocks()
-        if backward:
-            self._draw_scales(B)
-        else:
+        if not backward:
             self._scales = {}                             # forward only = evaluation mode: DropPath is the identity
+        elif draw:
+            self._draw_scales(B)
+        if self._plan is not None:
+            check(self.L.jirf_train_pack_plan_run(self._plan, self._s()))     # the weights may have changed since
         by_layer = [[b for b in blocks if b["layer"] == li] for li in range(9)]
         saved: Dict[str, dict] = {}
         xin = V(lq.data_ptr(), Cin * Pl[0], lq)
@@ -457,12 +569,18 @@ class AstTrainStep:
                   EP_RESID if self.dd_in == 3 else EP_STORE)
         # ---- loss (losses.py:12-14: smooth-L1, mean) and its gradient ----------------------------------------------
         dY = self.buf(B, self.in_chans, Pl[0])
-        loss = C.c_double()
+        # the loss stays on the device (a ring of slots, so that a value can be read many steps later); reading it on
+        # the host here would stall the queue in the middle of the step
+        if loss_out is None:
+            self._loss_slot = (self._loss_slot + 1) % self._loss_ring.numel()
+            loss_t = self._loss_ring[self._loss_slot]
+        else:
+            loss_t = loss_out
         check(self.L.jirf_train_smooth_l1(_vp(pred.ptr), _vp(gt.data_ptr()), _vp(dY.ptr if backward else None),
-                                          pred_t.numel(), self.loss_weight, C.byref(loss), self._s()))
-        self.last_loss = loss.value
+                                          pred_t.numel(), self.loss_weight, _vp(loss_t.data_ptr()), None, self._s()))
+        self.loss_tensor = loss_t
         if not backward:
-            return loss.value, pred_t
+            return loss_t, pred_t
         # ---- backward ---------------------------------------------------------------------------------------------------
         def layer_bwd(li: int, d: V) -> V:
             l = LEVEL[li]
@@ -500,7 +618,9 @@ class AstTrainStep:
         self.gelu_bwd(y0, None, d, dpre, None, B, E * Pl[0], 2)
         self.conv_dw(dpre, xin, self.G("input_proj.proj.0.weight"), self.G("input_proj.proj.0.bias"), B, E, Cin, H, W, H, W,
                      3, 1, 1)
-        return loss.value, pred_t
+        if self._plan is None:
+            self._build_pack_plan()                       # the step has listed every (weight, kind) pair it packs
+        return loss_t, pred_t
 
     # ---- the step (image_restoration_model.py:235-276) -------------------------------------------------------------
     def average_gradients(self) -> None:
@@ -510,6 +630,8 @@ class AstTrainStep:
         broadcast_flat_parameters(self.p, self.group, src)
 
     def kernel_timing(self, on: bool) -> None:
+        """Per-kernel device times (HIP events around every launch); while on, steps are queued kernel by kernel."""
+        self._timing = bool(on)
         check(self.L.jirf_train_kernel_timing(int(on)))
 
     def kernel_times(self) -> List[dict]:
@@ -533,12 +655,25 @@ class AstTrainStep:
                                           self.max_norm if clip else 0.0, self.lr, self.betas[0], self.betas[1], self.eps,
                                           self.iteration, self.torch_form, self._s()))
 
-    def optimize_parameters(self, lq: torch.Tensor, gt: torch.Tensor, current_iter: Optional[int] = None) -> float:
+    def optimize_parameters(self, lq: torch.Tensor, gt: torch.Tensor, current_iter: Optional[int] = None,
+                            sync_loss: bool = True):
+        """One iteration (image_restoration_model.py:235-276).  Returns this rank's loss: a float, read once the
+        whole step has been queued, or with sync_loss=False the 0-d device tensor that will hold it (valid for the
+        next 64 steps) - the reference's loss is a lazy Jittor variable too, evaluated when the logger prints it.
+        `log_loss` is the mean over the ranks (reduce_loss_dict), of the same kind."""
         self.iteration = int(current_iter) if current_iter is not None else self.iteration + 1
-        self.g.zero_()
-        loss, pred = self.forward_backward(lq, gt)
+        if self.use_graph and self._plan is not None and self.drop_scales is None and not self._timing:
+            loss_t, pred = self._captured_forward_backward(lq, gt)
+        else:
+            self.g.zero_()
+            loss_t, pred = self.forward_backward(lq, gt, sync_loss=False)
         self.output = pred
         self.average_gradients()
         self.apply_update()
-        self.log_loss = reduce_loss(loss, self.device, self.group)
-        return loss
+        self.log_loss = reduce_loss(loss_t, self.device, self.group)
+        if not sync_loss:
+            return loss_t
+        if isinstance(self.log_loss, torch.Tensor):
+            self.log_loss = float(self.log_loss.item())
+        self.last_loss = float(loss_t.item())
+        return self.last_loss

@@ -243,10 +243,12 @@ int jirf_train_kernel_times(const char** names_out, float* ms_out, double* flops
                             int capacity, int* n_out);
 
 /* Pixel loss of the shipped configurations: "L1Loss" is nn.smooth_l1_loss with mean reduction
- * (basicsr/models/losses/losses.py:12-14,44-52).  *loss_host = loss_weight * mean(l); grad (or NULL) receives
- * d loss / d pred = loss_weight * clamp(pred - target, -1, 1) / n.  Synchronises `stream`. */
+ * (basicsr/models/losses/losses.py:12-14,44-52).  loss = loss_weight * mean(l) goes to *loss_dev (device, or NULL)
+ * and to *loss_host (or NULL; a host destination synchronises `stream`, a device destination alone does not, so
+ * the caller can keep queueing the backward pass and read the loss later); grad (or NULL) receives
+ * d loss / d pred = loss_weight * clamp(pred - target, -1, 1) / n. */
 int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, long n, float loss_weight,
-                         double* loss_host, void* stream);
+                         double* loss_dev, double* loss_host, void* stream);
 /* Sum of squares of a flat buffer in double (the norm of Optimizer.clip_grad_norm,
  * image_restoration_model.py:269-270), to device and / or host memory (host: synchronises `stream`). */
 int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, void* stream);
@@ -274,9 +276,23 @@ int jirf_train_adam_step(float* p, const float* g, float* m, float* v, long n, c
 #define JIRF_W_BWD_DATA 1
 #define JIRF_W_DECONV 2
 #define JIRF_W_DOWN_BWD_DATA 4
+#define JIRF_W_PACKED 8 /* or-ed into w_kind: `w` is that kind's packed form, written by jirf_train_pack_plan_run */
 int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const float* bias, const float* r, long r_bs,
                     float* y, long y_bs, int B, int Cin, int Cout, int Hin, int Win, int ks, int stride, int pad,
                     int epi, void* stream);
+/* The packed forms of many weights in one launch.  Without a plan every jirf_train_conv call packs its weight
+ * by a kernel of its own (a few hundred small launches per AST step); a plan lists the (weight, kind) pairs of a
+ * step once - w[i] (device, reference layout), bias[i] (JIRF_W_DECONV only, or NULL), w_kind[i], Cin[i], Cout[i],
+ * ks[i] as they are passed to jirf_train_conv, and wt[i], a device buffer of jirf_train_packed_floats() floats
+ * that receives the packed form - and jirf_train_pack_plan_run() rewrites every wt[i] from the current weights
+ * (call it after each update of the weights).  jirf_train_conv then takes wt[i] with w_kind | JIRF_W_PACKED
+ * (and still the bias pointer).  The plan belongs to the device current at creation.  No counterpart in the
+ * reference, whose framework keeps its own weight layouts. */
+long jirf_train_packed_floats(int w_kind, int Cin, int Cout, int ks);   /* < 0: bad arguments */
+int jirf_train_pack_plan_create(int n, const float* const* w, const float* const* bias, float* const* wt,
+                                const int* w_kind, const int* Cin, const int* Cout, const int* ks, void** plan_out);
+int jirf_train_pack_plan_run(void* plan, void* stream);
+void jirf_train_pack_plan_destroy(void* plan);
 /* Weight and bias gradient of a convolution / Linear: dw [M][Cin][ks][ks] (+)= sum_{b,oy,ox} dy[b][o][oy][ox]
  * x[b][c][oy stride - pad + ky][ox stride - pad + kx], db [M] (+)= sum dy (db may be NULL).  Hout * Wout must be
  * a multiple of 16.  The weight gradient of the transposed convolution is this call with the roles swapped
@@ -311,6 +327,12 @@ int jirf_train_add(const float* a, long a_bs, const float* b, long b_bs, float* 
  * multiplied per sample by 0 or 1 / keep_prob. */
 int jirf_train_scale_add(const float* a, long a_bs, const float* b, long b_bs, const float* scale, float* y, long y_bs,
                          int B, long n_img, void* stream);
+/* The per-sample DropPath factors of a step, drawn on the device: out [rows][B], out[r][b] = 0 with probability
+ * rate[r] and 1 / (1 - rate[r]) otherwise (drop_path(), ast_arch.py:62-70); rate [rows] and counter [1] are device
+ * arrays.  The variates are a hash of (seed, *counter, r, b) and the call advances *counter, so the sequence is a
+ * function of the seed (the reference draws from Jittor's generator, whose stream is not reproduced). */
+int jirf_train_drop_path_scales(float* out, const float* rate, int rows, int B, unsigned long long seed,
+                                unsigned long long* counter, void* stream);
 /* out [C] (+)= sum_{b,p} x[b][c][p] (the bias gradient of the transposed convolution). */
 int jirf_train_channel_sum(const float* x, long x_bs, float* out, int B, int C, long P, int accumulate, void* stream);
 /* Depthwise 3x3 (zero pad 1, ast_arch.py:458-466) on device weights w [C,1,3,3], bias [C] or NULL; flip != 0 reverses

@@ -36,7 +36,9 @@ def test_smooth_l1_loss_and_gradient():
     g = torch.empty(n, device="cuda")
     out = C.c_double()
     pd_, td_ = dev(pred), dev(tgt)          # (held: a temporary's memory would be handed to the next allocation)
-    call("jirf_train_smooth_l1", ptr(pd_), ptr(td_), ptr(g), n, 0.7, C.byref(out), stream())
+    on_dev = torch.zeros(1, dtype=torch.float64, device="cuda")
+    call("jirf_train_smooth_l1", ptr(pd_), ptr(td_), ptr(g), n, 0.7, ptr(on_dev), C.byref(out), stream())
+    assert float(on_dev.item()) == out.value                 # the device copy of the loss (read later by the caller)
     assert abs(out.value - float(loss)) < 1e-6 * abs(float(loss))
     assert rel_err(g.cpu().numpy(), pt.grad.numpy()) < 1e-6
     assert (np.abs(pred - tgt) > 1).any() and (np.abs(pred - tgt) < 1).any()      # both branches
@@ -240,6 +242,49 @@ def test_transposed_convolution_forward_and_both_gradients(B, Cin, Cout, H):
     call("jirf_train_channel_sum", ptr(dyd), 0, ptr(db), B, Cout, 4 * H * H, 0, stream())
     assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < REL
     assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < REL
+
+
+def test_pack_plan_equals_packing_inside_the_call():
+    """One launch packs every (weight, kind) pair of a plan; jirf_train_conv on the packed buffers (w_kind |
+    JIRF_W_PACKED) gives bit for bit what the same call gives when it packs its weight itself: all four kinds,
+    3 x 3 / 1 x 1 / 4 x 4 stride 2 / transposed, odd channel counts, and again after the weights have changed."""
+    from jirf_hip import lib
+    L = lib()
+    W_PACKED = 8
+    B, H = 2, 16
+    # (kind, Cin, Cout, ks, stride, pad, weight shape, Hin of the call)
+    cases = [(W_FWD, 24, 40, 3, 1, 1, (40, 24, 3, 3), H), (W_FWD, 130, 70, 1, 1, 0, (70, 130), H),
+             (W_FWD, 16, 32, 4, 2, 1, (32, 16, 4, 4), H), (W_BWD_DATA, 40, 24, 3, 1, 1, (40, 24, 3, 3), H),
+             (W_BWD_DATA, 70, 130, 1, 1, 0, (70, 130), H), (W_DECONV, 64, 32, 1, 1, 0, (64, 32, 2, 2), 8),
+             (W_DOWN_BWD, 32, 16, 1, 1, 0, (32, 16, 4, 4), 8)]
+    ws = [dev(rnd(*c[6], scale=0.2, seed=10 + i)) for i, c in enumerate(cases)]
+    bias = dev(rnd(32, seed=5))
+    sizes = [int(L.jirf_train_packed_floats(c[0], c[1], c[2], c[3])) for c in cases]
+    assert min(sizes) > 0 and L.jirf_train_packed_floats(3, 8, 8, 1) < 0
+    bufs = [torch.full((n,), float("nan"), device="cuda") for n in sizes]
+    n = len(cases)
+    arr_p, arr_i = C.c_void_p * n, C.c_int * n
+    plan = C.c_void_p()
+    call("jirf_train_pack_plan_create", n, arr_p(*[w.data_ptr() for w in ws]),
+         arr_p(*[bias.data_ptr() if c[0] == W_DECONV else None for c in cases]), arr_p(*[b.data_ptr() for b in bufs]),
+         arr_i(*[c[0] for c in cases]), arr_i(*[c[1] for c in cases]), arr_i(*[c[2] for c in cases]),
+         arr_i(*[c[3] for c in cases]), C.byref(plan))
+    try:
+        for trial in range(2):
+            call("jirf_train_pack_plan_run", plan, stream())
+            for (kind, Cin, Cout, ks, stride, pad, _, Hin), w, wt in zip(cases, ws, bufs):
+                x = dev(rnd(B, Cin, Hin, Hin, seed=40 + trial))
+                Ho = 2 * Hin if kind in (W_DECONV, W_DOWN_BWD) else (Hin + 2 * pad - ks) // stride + 1
+                bd = bias if kind == W_DECONV else None
+                y0 = torch.empty(B, Cout, Ho, Ho, device="cuda")
+                y1 = torch.empty_like(y0)
+                _conv(x, w, kind, bd, y0, B, Cin, Cout, Hin, Hin, ks, stride, pad)
+                _conv(x, wt, kind | W_PACKED, bd, y1, B, Cin, Cout, Hin, Hin, ks, stride, pad)
+                assert torch.isfinite(y1).all() and torch.equal(y0, y1), (kind, Cin, Cout, ks)
+            for w in ws:                                  # a weight update: the next run repacks
+                w.mul_(0.5).add_(0.01)
+    finally:
+        L.jirf_train_pack_plan_destroy(plan)
 
 
 @pytest.mark.parametrize("coupled", [0, 1])

@@ -217,6 +217,28 @@ def test_stochastic_depth_draws():
     assert z._scales == {}
 
 
+def test_captured_step_equals_the_step_queued_kernel_by_kernel():
+    """use_graph=True replays forward + backward as one hipGraph from the second iteration on: same kernels on the
+    same data in the same order, so weights and losses are bit-identical to the eager trainer's, with stochastic
+    depth on (the factors are drawn on the device from the seed, outside the captured region) and across a change
+    of input shape (a new capture)."""
+    from jirf_hip.train import AstTrainStep
+    cfg = _cfg()
+    sd = _state(cfg, 6)
+    eager = AstTrainStep(cfg, sd, seed=3)
+    graph = AstTrainStep(cfg, sd, seed=3, use_graph=True)
+    assert eager.drop_path_rate == graph.drop_path_rate == pytest.approx(0.1)
+    shapes = [(2, 128)] * 4 + [(1, 128)] * 2 + [(2, 128)]
+    for it, (B, S) in enumerate(shapes, start=1):
+        lq, gt = _data(B, S, 50 + it)
+        a = eager.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), it)
+        b = graph.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), it)
+        assert a == b, (it, a, b)
+        assert torch.equal(eager.output, graph.output)
+    assert graph._graph is not None
+    assert torch.equal(eager.p, graph.p) and torch.equal(eager.m, graph.m) and torch.equal(eager.v, graph.v)
+
+
 def test_gradient_mean_over_two_shards_equals_the_batch_gradient():
     """What the data-parallel step relies on: with per-image semantics the gradient of the mean loss over a batch is
     the mean of the gradients of its shards (here the two halves a 2-rank job would hold), so averaging the flat
