@@ -538,118 +538,121 @@ __global__ __launch_bounds__(256) void batch_mean_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // 2. slab reduction, correlation row means, reciprocal norms
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum_double(double v, double* red) {
-  const int tid = threadIdx.x;
-  red[tid] = v;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  const double r = red[0];
-  __syncthreads();
-  return r;
-}
-
-// Sums the split-K slabs of every matrix / vector element into slab 0.  32 elements per
-// workgroup, 8 threads per element: thread `part` adds slabs part, part + 8, ... in order, the
-// eight partial sums are then added in order, so the result does not depend on scheduling.
-template <typename T>
+// Sums the split-K slabs of every matrix / vector element into slab 0.  A workgroup takes 256 / PARTS
+// elements with PARTS threads per element: thread `part` adds slabs part, part + PARTS, ... in order, the
+// partial sums are then added in order, so the result does not depend on scheduling.
+template <typename T, int PARTS>
 __device__ __forceinline__ void reduce_slabs_part(T* __restrict__ base, long stride, int splits,
                                                   int part, T* __restrict__ red, int el, bool on) {
+  constexpr int EL = 256 / PARTS;
   T t = 0;
   if (on) {
     // four loads in flight per thread (clamped, unpredicated), added in slab order
-    for (int sp0 = part; sp0 < splits; sp0 += 32) {
+    for (int sp0 = part; sp0 < splits; sp0 += 4 * PARTS) {
       T v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = base[(long)min(sp0 + 8 * u, splits - 1) * stride];
+      for (int u = 0; u < 4; ++u) v[u] = base[(long)min(sp0 + PARTS * u, splits - 1) * stride];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (sp0 + 8 * u < splits) t += v[u];
+        if (sp0 + PARTS * u < splits) t += v[u];
     }
   }
-  red[part * 32 + el] = t;
+  red[part * EL + el] = t;
   __syncthreads();
   if (on && part == 0) {
     T u = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) u += red[q * 32 + el];
+    for (int q = 0; q < PARTS; ++q) u += red[q * EL + el];
     base[0] = u;
   }
   __syncthreads();
 }
 
+template <int PARTS>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ qk_part,
                                                            double* __restrict__ gram_part,
                                                            double* __restrict__ qsum_part,
                                                            float* __restrict__ q2_part,
                                                            float* __restrict__ k2_part, int C,
                                                            int splits, int B, int G) {
+  constexpr int EL = 256 / PARTS;
   __shared__ double red_d[256];
   __shared__ float red_f[256];
-  const int el = threadIdx.x & 31, part = threadIdx.x >> 5;
-  const long e = (long)blockIdx.x * 32 + el;
+  const int el = threadIdx.x % EL, part = threadIdx.x / EL;
+  const long e0 = (long)blockIdx.x * EL, e = e0 + el;
   const int b = blockIdx.y;
   const long CC = (long)C * C;
-  // matrices: elements [0, CC); vectors: elements [CC, CC + C)  (block-uniform split: CC % 32 == 0
-  // is not assumed, so both branches are evaluated per thread with `on` masks)
+  // matrices: elements [0, CC); vectors: elements [CC, CC + C).  A workgroup may straddle the boundary, so
+  // each kind has a per-thread mask; kinds with no element in this workgroup are skipped (uniform branch).
   const bool mat = e < CC, vec = e >= CC && e < CC + C;
+  const bool any_mat = e0 < CC, any_vec = e0 + EL > CC;
   const long c = e - CC;
-  reduce_slabs_part<float>(qk_part + (long)b * splits * CC + (mat ? e : 0), CC, splits, part, red_f, el, mat && b < B);
-  if (gram_part)
-    reduce_slabs_part<double>(gram_part + (long)(b < G ? b : 0) * splits * CC + (mat ? e : 0), CC, splits, part, red_d, el,
-                              mat && b < G);
-  reduce_slabs_part<float>(q2_part + (long)b * splits * C + (vec ? c : 0), C, splits, part, red_f, el, vec && b < B);
-  reduce_slabs_part<float>(k2_part + (long)b * splits * C + (vec ? c : 0), C, splits, part, red_f, el, vec && b < B);
-  if (qsum_part)
-    reduce_slabs_part<double>(qsum_part + (long)(b < G ? b : 0) * splits * C + (vec ? c : 0), C, splits, part, red_d, el,
-                              vec && b < G);
+  if (any_mat) {
+    reduce_slabs_part<float, PARTS>(qk_part + (long)b * splits * CC + (mat ? e : 0), CC, splits, part, red_f, el, mat && b < B);
+    if (gram_part)
+      reduce_slabs_part<double, PARTS>(gram_part + (long)(b < G ? b : 0) * splits * CC + (mat ? e : 0), CC, splits, part, red_d, el,
+                                       mat && b < G);
+  }
+  if (any_vec) {
+    reduce_slabs_part<float, PARTS>(q2_part + (long)b * splits * C + (vec ? c : 0), C, splits, part, red_f, el, vec && b < B);
+    reduce_slabs_part<float, PARTS>(k2_part + (long)b * splits * C + (vec ? c : 0), C, splits, part, red_f, el, vec && b < B);
+    if (qsum_part)
+      reduce_slabs_part<double, PARTS>(qsum_part + (long)(b < G ? b : 0) * splits * C + (vec ? c : 0), C, splits, part, red_d, el,
+                                       vec && b < G);
+  }
 }
 
 static void launch_reduce_slabs(float* qk_part, double* gram_part, double* qsum_part, float* q2_part,
                                 float* k2_part, int C, int splits, int B, int G, hipStream_t s) {
   if (splits <= 1) return;
   const long n = (long)C * C + C;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 31) / 32), std::max(B, G)), dim3(256), 0, s,
+  // (32 threads per element, 8 elements per workgroup, was measured slower at 256 slabs: 32-byte segments)
+  hipLaunchKernelGGL(reduce_slabs_kernel<8>, dim3((unsigned)((n + 31) / 32), std::max(B, G)), dim3(256), 0, s,
                      qk_part, gram_part, qsum_part, q2_part, k2_part, C, splits, B, G);
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
+// One wave per channel row i (four rows per workgroup): sums the slabs of row i of Q K^T, the reciprocal
+// norms, and (when sim != null) the mean of row i of the correlation matrix in double.  The per-channel
+// means and standard deviations are formed once per workgroup by all of its threads.
+constexpr int RG_ROWS = 4;
 __global__ __launch_bounds__(256) void regroup_rows_kernel(
     const float* __restrict__ qk_part, const double* __restrict__ gram_part,
     const double* __restrict__ qsum_part, const float* __restrict__ q2_part,
     const float* __restrict__ k2_part, float* __restrict__ s_qk, float* __restrict__ rq,
     float* __restrict__ rk, double* __restrict__ sim, int C, int P, int splits, int nsum, int ipg,
     float norm_add) {
-  extern __shared__ double dsm[];  // mean[C], dstd[C], red[256]
+  extern __shared__ double dsm[];  // mean[C], dstd[C]
   double* mean = dsm;
   double* dstd = dsm + C;
-  double* red = dsm + 2 * C;
-  const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * RG_ROWS + wave;
+  const bool row_on = i < C;
 
-  for (int j = tid; j < C; j += 256) {
-    float s = 0.f;
+  if (row_on) {
+    for (int j = lane; j < C; j += 64) {
+      float s = 0.f;
 #pragma unroll 8
-    for (int sp = 0; sp < nsum; ++sp) s += qk_part[(((long)b * splits + sp) * C + i) * C + j];
-    s_qk[((long)b * C + i) * C + j] = s;
-  }
-  if (tid == 0) {
-    float q2 = 0.f, k2 = 0.f;
+      for (int sp = 0; sp < nsum; ++sp) s += qk_part[(((long)b * splits + sp) * C + i) * C + j];
+      s_qk[((long)b * C + i) * C + j] = s;
+    }
+    if (lane == 0) {
+      float q2 = 0.f, k2 = 0.f;
 #pragma unroll 8
-    for (int sp = 0; sp < nsum; ++sp) {
-      q2 += q2_part[((long)b * splits + sp) * C + i];
-      k2 += k2_part[((long)b * splits + sp) * C + i];
-    }
-    if (norm_add > 0.f) {
-      rq[(long)b * C + i] = 1.0f / (sqrtf(q2) + norm_add);
-      rk[(long)b * C + i] = 1.0f / (sqrtf(k2) + norm_add);
-    } else {
-      rq[(long)b * C + i] = 1.0f / sqrtf(fmaxf(q2, NORM_EPS));
-      rk[(long)b * C + i] = 1.0f / sqrtf(fmaxf(k2, NORM_EPS));
+      for (int sp = 0; sp < nsum; ++sp) {
+        q2 += q2_part[((long)b * splits + sp) * C + i];
+        k2 += k2_part[((long)b * splits + sp) * C + i];
+      }
+      if (norm_add > 0.f) {
+        rq[(long)b * C + i] = 1.0f / (sqrtf(q2) + norm_add);
+        rk[(long)b * C + i] = 1.0f / (sqrtf(k2) + norm_add);
+      } else {
+        rq[(long)b * C + i] = 1.0f / sqrtf(fmaxf(q2, NORM_EPS));
+        rk[(long)b * C + i] = 1.0f / sqrtf(fmaxf(k2, NORM_EPS));
+      }
     }
   }
-  if (sim == nullptr || b % ipg != 0) return;
+  if (sim == nullptr || b % ipg != 0) return;   // uniform over the workgroup
   const int g = b / ipg;
   const double L = (double)P;
   for (int j = tid; j < C; j += 256) {
@@ -664,16 +667,18 @@ __global__ __launch_bounds__(256) void regroup_rows_kernel(
     dstd[j] = sqrt((gjj - L * m * m) / (L - 1.0));
   }
   __syncthreads();
+  if (!row_on) return;
   double acc = 0.0;
   const double mi = mean[i], di = dstd[i];
-  for (int j = tid; j < C; j += 256) {
+  for (int j = lane; j < C; j += 64) {
     double gij = 0.0;
 #pragma unroll 8
     for (int sp = 0; sp < nsum; ++sp) gij += gram_part[(((long)g * splits + sp) * C + i) * C + j];
     acc += ((gij - L * mi * mean[j]) / (L - 1.0)) / (di * dstd[j]);
   }
-  const double tot = block_sum_double(acc, red);
-  if (tid == 0) sim[(long)g * C + i] = tot / (double)C;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) sim[(long)g * C + i] = acc / (double)C;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -738,6 +743,35 @@ constexpr int GM_THREADS = 1024;   // modulation kernel: one 32-row output tile 
 
 __device__ __forceinline__ double sort_key(double v) { return v != v ? -INFINITY : v; }
 
+// ---- 3b. the cache pooled to every group's c x c (Inter_CacheModulation.align) ---------------------
+// 256 outputs per workgroup; the rows of a window are summed with independent loads in flight (clamped,
+// unpredicated), in the order y-major / x-minor of the plain double loop.
+__device__ __forceinline__ void pool_groups_block(const GroupAttnArgs& a, int blk, int g) {
+  const int idx = blk * 256 + threadIdx.x;
+  if (idx >= a.psum) return;
+  int gi = 3;
+  while (gi > 0 && idx < a.poff[gi]) --gi;
+  const int c = a.gsz[gi], C = a.C;
+  const int e = idx - a.poff[gi];
+  const int r = e / c, s = e - r * c;
+  const float* __restrict__ src = a.pooled + (long)g * C * C;
+  const int ys = pool_start(r, C, c), ye = pool_end(r, C, c);
+  const int xs = pool_start(s, C, c), xe = pool_end(s, C, c);
+  double acc = 0.0;
+  for (int y = ys; y < ye; ++y) {
+    const float* __restrict__ row = src + (long)y * C;
+    for (int x0 = xs; x0 < xe; x0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = row[min(x0 + u, xe - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (x0 + u < xe) acc += (double)v[u];
+    }
+  }
+  const_cast<float*>(a.pooled_g)[(long)g * a.psum + idx] = (float)(acc / (double)((ye - ys) * (xe - xs)));
+}
+
 // ---- 3a. permutation, gather, scale, row softmax ---------------------------------------------------
 // One workgroup per (group, chunk of sm_rc rows, image); every workgroup ranks the channels itself (a
 // few microseconds, cheaper than a launch of its own).  Writes the softmax rows in natural orientation;
@@ -746,6 +780,12 @@ __device__ __forceinline__ double sort_key(double v) { return v != v ? -INFINITY
 // this chunk is zeroed (the last chunk of the last group also owns the padding rows).
 __global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ga_smem[];
+  // workgroups past the softmax chunks pool the cache for the modulation kernel (independent of the
+  // softmax, so it rides in this launch instead of one of its own)
+  if ((int)blockIdx.x >= a.sm_chunks) {
+    if (blockIdx.y % a.ipg == 0) pool_groups_block(a, blockIdx.x - a.sm_chunks, blockIdx.y / a.ipg);
+    return;
+  }
   const int gi = a.sm_g[blockIdx.x], r0 = a.sm_r0[blockIdx.x], b = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, c = a.gsz[gi], off = a.goff[gi];
   const int rc = min(a.sm_rc, c - r0);
@@ -826,25 +866,6 @@ __global__ __launch_bounds__(256) void group_softmax_kernel(const GroupAttnArgs 
       const int s = e / rc, r = e - s * rc;
       att_t[(long)(off + s) * a.Mpad + off + r0 + r] = X[r * ld + s];
     }
-}
-
-// ---- 3b. the cache pooled to every group's c x c (Inter_CacheModulation.align) ---------------------
-__global__ __launch_bounds__(256) void cache_pool_groups_kernel(const GroupAttnArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int g = blockIdx.y;
-  if (idx >= a.psum) return;
-  int gi = 3;
-  while (gi > 0 && idx < a.poff[gi]) --gi;
-  const int c = a.gsz[gi], C = a.C;
-  const int e = idx - a.poff[gi];
-  const int r = e / c, s = e - r * c;
-  const float* __restrict__ src = a.pooled + (long)g * C * C;
-  const int ys = pool_start(r, C, c), ye = pool_end(r, C, c);
-  const int xs = pool_start(s, C, c), xe = pool_end(s, C, c);
-  double acc = 0.0;
-  for (int y = ys; y < ye; ++y)
-    for (int x = xs; x < xe; ++x) acc += (double)src[(long)y * C + x];
-  const_cast<float*>(a.pooled_g)[(long)g * a.psum + idx] = (float)(acc / (double)((ye - ys) * (xe - xs)));
 }
 
 // ---- 3c. inter-cache modulation -----------------------------------------------------------------------
@@ -1125,15 +1146,17 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
   {
     Scope scope("hint_regroup_rows", 3.0 * C * (double)C * sh.splits * B,
                 (double)C * C * sh.splits * (4.0 * B + 8.0 * G), s);
-    const size_t smem = (2 * (size_t)C + 256) * sizeof(double);
+    const size_t smem = 2 * (size_t)C * sizeof(double);
     launch_reduce_slabs(sc.qk_part, sc.gram_part, sc.qsum_part, q2_part, k2_part, C, sh.splits, B, G, s);
-    hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), smem, s, sc.qk_part, sc.gram_part,
+    hipLaunchKernelGGL(regroup_rows_kernel, dim3((C + RG_ROWS - 1) / RG_ROWS, B), dim3(256), smem, s, sc.qk_part, sc.gram_part,
                        sc.qsum_part, q2_part, k2_part, sc.s_qk, sc.rq, sc.rk, sim, C, P, sh.splits, 1,
                        ipg, 0.f);
     JIRF_HIP_CHECK(hipGetLastError());
   }
   const float* pooled = nullptr;
-  if (cache_in) {
+  if (cache_in && cache_c == C) {
+    pooled = cache_in;   // AdaptiveAvgPool2d to the same size is the identity: no copy
+  } else if (cache_in) {
     Scope scope("hint_cache_pool", 0.0, 4.0 * G * ((double)cache_c * cache_c + (double)C * C), s);
     hipLaunchKernelGGL(cache_pool_kernel, dim3((C * C + 255) / 256, G), dim3(256), 0, s, cache_in,
                        cache_c, sc.pooled, C);
@@ -1181,16 +1204,14 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     allow_dynamic_lds(once_softmax, reinterpret_cast<const void*>(group_softmax_kernel), 160 * 1024);
     allow_dynamic_lds(once_modulate, reinterpret_cast<const void*>(group_modulate_kernel), 160 * 1024);
     {
-      Scope scope(intern_label("hint_group_softmax C%d", C), 0.0, 12.0 * B * (double)C * C, s);
-      hipLaunchKernelGGL(group_softmax_kernel, dim3(ga.sm_chunks, B), dim3(256), smem_a, s, ga);
+      // with a cache: (psum + 255) / 256 more workgroups per image pool it to the groups' sizes
+      const int pool_blocks = pooled ? (psum + 255) / 256 : 0;
+      Scope scope(intern_label("hint_group_softmax C%d", C), 0.0,
+                  12.0 * B * (double)C * C + (pooled ? 4.0 * G * ((double)C * C + psum) : 0.0), s);
+      hipLaunchKernelGGL(group_softmax_kernel, dim3(ga.sm_chunks + pool_blocks, B), dim3(256), smem_a, s, ga);
       JIRF_HIP_CHECK(hipGetLastError());
     }
     if (pooled) {
-      {
-        Scope scope("hint_cache_pool_groups", 0.0, 4.0 * G * ((double)C * C + psum), s);
-        hipLaunchKernelGGL(cache_pool_groups_kernel, dim3((psum + 255) / 256, G), dim3(256), 0, s, ga);
-        JIRF_HIP_CHECK(hipGetLastError());
-      }
       double fl = 0.0;
       for (int i = 0; i < 4; ++i) fl += 6.0 * sh.gsz[i] * (double)sh.gsz[i] * sh.gsz[i];
       Scope scope(intern_label("hint_group_modulate C%d", C), fl * B, 16.0 * B * (double)psum, s);
@@ -1342,7 +1363,7 @@ void launch_head_attention(int B, int C, int P, int heads, TV q, TV k, const flo
   {
     Scope scope("head_reduce_rows", 1.0 * C * (double)C * splits * B, 4.0 * C * (double)C * splits * B, s);
     launch_reduce_slabs(sc.qk_part, nullptr, nullptr, sc.q2_part, sc.k2_part, C, splits, B, 0, s);
-    hipLaunchKernelGGL(regroup_rows_kernel, dim3(C, B), dim3(256), 0, s, sc.qk_part, nullptr, nullptr,
+    hipLaunchKernelGGL(regroup_rows_kernel, dim3((C + RG_ROWS - 1) / RG_ROWS, B), dim3(256), 0, s, sc.qk_part, nullptr, nullptr,
                        sc.q2_part, sc.k2_part, sc.s_qk, sc.rq, sc.rk, nullptr, C, P, splits, 1, 1, norm_add_eps);
     JIRF_HIP_CHECK(hipGetLastError());
   }
