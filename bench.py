@@ -298,7 +298,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="256x256 crops per GPU per step")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="256x256 crops per GPU per step (images are independent units: the batch only sets how many "
+                         "are in flight; 16 -> 32 gains 3.5 %, 32 -> 64 nothing)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--height", type=int, default=0, help="image height (default: --size)")
     ap.add_argument("--width", type=int, default=0, help="image width (default: --size)")
@@ -471,7 +473,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra_configs and not args.host_io and \
             (args.arch, Hh, Ww, args.crop_size) == ("HINT", 256, 256, 0):
         nets = {"HINT": net}
-        extra = [("HINT", 1, 256, 256, 20, 0, 0), ("HINT", 1, 720, 1280, 4, 0, 0),
+        extra = [("HINT", 16, 256, 256, 6, 0, 0), ("HINT", 1, 256, 256, 20, 0, 0), ("HINT", 1, 720, 1280, 4, 0, 0),
                  ("AST", 16, 256, 256, 6, 0, 0), ("AST", 1, 256, 256, 20, 0, 0), ("AST", 1, 321, 481, 10, 0, 0),
                  ("ASTv2", 1, 321, 481, 10, 0, 0), ("FPro", 1, 460, 620, 6, 256, 158)]
         out["configs"] = []

@@ -1,6 +1,6 @@
 """Run ONE launch shape of the LayerNorm + 1x1 GEMM (the dominant kernel of the HINT benchmark)
 a few times, so that a `rocprofv3 --pmc` pass over this program attributes its counters to that
-shape only.  Usage: python3 profiles/pmc_op.py [B Cin Cout P] (default 16 96 510 65536)."""
+shape only.  Usage: python3 profiles/pmc_op.py [B Cin Cout P] (default 32 96 510 65536)."""
 import os
 import sys
 
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import jirf_hip  # noqa: E402
 import ctypes  # noqa: E402
 
-B, C, M, P = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (16, 96, 510, 65536)
+B, C, M, P = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (32, 96, 510, 65536)
 rng = np.random.default_rng(0)
 x = torch.from_numpy(rng.standard_normal((B, C, P), dtype=np.float32)).cuda()
 lw = torch.ones(C, device="cuda")

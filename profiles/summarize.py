@@ -7,6 +7,7 @@ import sqlite3
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 32   # crops per step of the benchmark the traces were taken on
 src = f"gpurun_out/prof_{tag}"
 dst = "profiles"
 
@@ -28,11 +29,11 @@ for name, gx, gy, wx, dur in rows:
     b[0] += 1
     b[1] += dur
 total = sum(v[1] for v in by_sym.values())
-with open(os.path.join(dst, f"{tag}_hint_b16_kernel_stats.csv"), "w") as fh:
+with open(os.path.join(dst, f"{tag}_hint_b{BATCH}_kernel_stats.csv"), "w") as fh:
     fh.write("kernel,calls,total_ns,avg_ns,percent\n")
     for k, (n, t) in sorted(by_sym.items(), key=lambda kv: -kv[1][1]):
         fh.write(f"\"{short(k)}\",{n},{t},{t / n:.0f},{100.0 * t / total:.2f}\n")
-with open(os.path.join(dst, f"{tag}_hint_b16_kernel_stats_by_grid.csv"), "w") as fh:
+with open(os.path.join(dst, f"{tag}_hint_b{BATCH}_kernel_stats_by_grid.csv"), "w") as fh:
     fh.write("kernel,grid_x,grid_y,workgroup_x,calls,total_ns,avg_ns,percent\n")
     for (k, gx, gy, wx), (n, t) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
         fh.write(f"\"{short(k)}\",{gx},{gy},{wx},{n},{t},{t / n:.0f},{100.0 * t / total:.2f}\n")
@@ -105,8 +106,8 @@ with open(os.path.join("image-restoration_amd", "csrc", "gemm.hip"), "rb") as _f
 with open(os.path.join("image-restoration_amd", "csrc", "common.h")) as _fh:
     _t = _fh.read()
 _h.update(_t[_t.index("struct GemmArgs {"):_t.index("void launch_gemm(")].encode())
-res = {"kernel_source_sha256": _h.hexdigest(), "isolated_kernel_trace": iso, "sq_counters": sq, "op": "gemm_ln_1x1 M510 K96 P65536 (B=16): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
-       "algorithmic_bytes_per_launch": 4.0 * 16 * 65536 * (96 + 510),
+res = {"kernel_source_sha256": _h.hexdigest(), "isolated_kernel_trace": iso, "sq_counters": sq, "op": f"gemm_ln_1x1 M510 K96 P65536 (B={BATCH}): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
+       "algorithmic_bytes_per_launch": 4.0 * BATCH * 65536 * (96 + 510),
        "kernels": out}
 with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
     json.dump(res, fh, indent=1)
