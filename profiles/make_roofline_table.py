@@ -20,4 +20,4 @@ print("| ms/step | share | launches | kernel + shape | TFLOP/s | GB/s | bound | 
 print("|---:|---:|---:|---|---:|---:|---|---:|")
 for ms, n, name, tf, gbs, bound, frac in rows:
     print(f"| {ms:.3f} | {100 * ms / tot:.1f} % | {n} | `{name}` | {tf:.1f} | {gbs:.0f} | {bound} | {frac:.2f} |")
-print(f"\nTotal {tot:.1f} ms of kernel time per step (batch of 16 images).")
+print(f"\nTotal {tot:.1f} ms of kernel time per step.")
