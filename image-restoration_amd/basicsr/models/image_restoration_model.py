@@ -70,9 +70,17 @@ class ImageCleanModel:
                                        eps=float(optim.get("eps", 1e-8)),
                                        use_grad_clip=bool(train_opt.get("use_grad_clip", False)),
                                        loss_weight=float(pix.get("loss_weight", 1.0)),
-                                       seed=int(self.opt.get("manual_seed", 0) or 0))
+                                       # basicsr/train.py:63-67 seeds every process with manual_seed + rank
+                                       seed=int(self.opt.get("manual_seed", 0) or 0) + self._rank(),
+                                       # a step is replayed as one captured hipGraph from its second run on
+                                       use_graph=bool(train_opt.get("use_graph", True)))
         self.train_step.broadcast_parameters()
         self.log_dict = OrderedDict()
+
+    @staticmethod
+    def _rank() -> int:
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
     def set_learning_rate(self, lr: float):
         self.train_step.lr = float(lr)
