@@ -1,5 +1,5 @@
 """Parity at the benchmark's own configurations (not proxies of them): the full HINT network on a batch
-of 256 x 256 crops with per-image semantics, the full AST network on a 481 x 321 image through the
+of 256 x 256 crops with per-image semantics and on one 1280 x 720 image, the full AST network on a 481 x 321 image through the
 enclosing-square policy (512 x 512), and a measured account of what HINT's argsort discontinuity does
 when the channel orders are left free-running at 256 x 256.  Oracle = oracle/ (CPU restatement of the
 reference; parity unpinned, see its headers)."""
@@ -67,6 +67,31 @@ def test_hint_benchmark_configuration():
     assert err < TOL
     for i in range(B):
         assert abs(psnr(y[i:i + 1], x[i:i + 1]) - psnr(y_ref[i:i + 1], x[i:i + 1])) < 0.01
+
+
+def test_hint_720p_full_configuration():
+    """BASELINE configs[3]: the full HINT network on one 1280 x 720 image (the long H W axis of the channel
+    attention: 921 600 pixels per contraction at the first level), cold start, against the oracle on the same
+    image with the channel orders pinned to the oracle's.  The oracle takes about 20 s on the GPU box's host cores."""
+    cfg = ho.default_config()
+    sd = make_hint_state(cfg, seed=1, gain=0.6)
+    x = synthetic_images(1, 720, 1280, seed=104, sigma=50)
+    y_ref, names, perms, gaps = _hint_oracle(sd, x, cfg)
+    net = _hint(cfg, sd, "per_image")
+    net.native().plan(1, 720, 1280, 0)
+    net.force_perms([p[None] for p in perms])
+    y = net(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = max_abs(y, y_ref)
+    # free-running orders beside it: how many blocks agree with the oracle without being told
+    net.force_perms(None)
+    net.qv_cache = None
+    y_free = net(torch.from_numpy(x).cuda()).cpu().numpy()
+    got = net.last_perms(1)
+    same = sum(int(np.array_equal(got[i][0], perms[i])) for i in range(len(names)))
+    print(f"[HINT full 1280x720 B=1, pinned orders] max|dy| = {err:.2e}; free-running: {same} of {len(names)} orders "
+          f"equal the oracle's (min oracle gap {min(gaps):.2e}), max|dy| = {max_abs(y_free, y_ref):.2e}")
+    assert err < TOL
+    assert abs(psnr(y, x) - psnr(y_ref, x)) < 0.01
 
 
 def test_hint_free_running_orders_at_256():
