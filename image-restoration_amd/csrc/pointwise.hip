@@ -676,7 +676,10 @@ void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int 
 // As a GEMM this shape wastes 61 of 64 tile rows.  Here a lane owns 4 adjacent pixels and R rows and
 // keeps COUT x R x 4 accumulators; per input channel it loads R + 2 row segments (float4 + the two
 // neighbours from the adjacent lanes) and the 9 x COUT weights arrive as scalar loads.
-template <int COUT, int R>
+// CSPLIT: a single small image gives the chip one wave per CU, each walking all input channels one
+// load round trip after the other; then the four waves of a workgroup share one tile, wave w taking
+// channels w, w + 4, ..., and their partial sums meet in LDS in wave order (fixed order: reproducible).
+template <int COUT, int R, bool CSPLIT = false>
 __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __restrict__ x, long x_bs,
                                                              const float* __restrict__ wt, int Mpad,
                                                              const float* __restrict__ bias,
@@ -685,8 +688,9 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __rest
                                                              int H, int W, int lx_log2, int tiles_x,
                                                              int n_tasks) {
   const int lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (task >= n_tasks) return;  // whole wave
+  const int wave = threadIdx.x >> 6;
+  const int task = CSPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  if (task >= n_tasks) return;  // whole wave (CSPLIT: whole workgroup)
   const int b = blockIdx.y;
   const int LX = 1 << lx_log2, RW = 64 >> lx_log2;
   const int tx = task % tiles_x, ts = task / tiles_x;
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[o][i][j] = 0.f;
   const float* __restrict__ xb = x + (long)b * x_bs;
-  for (int c = 0; c < Cin; ++c) {
+  for (int c = CSPLIT ? wave : 0; c < Cin; c += CSPLIT ? 4 : 1) {
     const float* __restrict__ plane = xb + (long)c * P;
     float wv[9][COUT];
 #pragma unroll
@@ -734,6 +738,27 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __rest
 #pragma unroll
             for (int o = 0; o < COUT; ++o)
               acc[o][i][j] = fmaf(wv[ky * 3 + kx][o], row[i + ky][j + kx], acc[o][i][j]);
+  }
+  if constexpr (CSPLIT) {
+    __shared__ float part[3][COUT * R * 4][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int o = 0; o < COUT; ++o)
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) part[wave - 1][(o * R + i) * 4 + j][lane] = acc[o][i][j];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int o = 0; o < COUT; ++o)
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[o][i][j] += part[w][(o * R + i) * 4 + j][lane];
   }
   if (!x_ok) return;
 #pragma unroll
@@ -777,6 +802,22 @@ bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
   if (a.M >= 8 && (long)n_tasks * a.B < 1024) return false;
   const dim3 grid((unsigned)((n_tasks + 3) / 4), a.B), block(256);
   const float* res = a.epi == EP_RESID ? a.r.p : nullptr;
+  // a single small image (R is already 1): the input channels are split over the four waves of a workgroup
+  if (a.M <= 4 && R == 1 && (long)n_tasks * a.B < 512 && a.Cin >= 16) {
+    const dim3 grid1((unsigned)n_tasks, a.B);
+#define JIRF_FEWOUT_CS(CO)                                                                                     \
+  hipLaunchKernelGGL((conv3x3_fewout_kernel<CO, 1, true>), grid1, block, 0, s, a.x.p, a.x.bs, a.wt, a.Mpad, a.bias, \
+                     res, a.r.bs, a.y.p, a.y.bs, a.Cin, H, W, lx_log2, tiles_x, n_tasks)
+    switch (a.M) {
+      case 1: JIRF_FEWOUT_CS(1); break;
+      case 2: JIRF_FEWOUT_CS(2); break;
+      case 3: JIRF_FEWOUT_CS(3); break;
+      default: JIRF_FEWOUT_CS(4); break;
+    }
+#undef JIRF_FEWOUT_CS
+    JIRF_HIP_CHECK(hipGetLastError());
+    return true;
+  }
 #define JIRF_FEWOUT(CO, RR)                                                                            \
   hipLaunchKernelGGL((conv3x3_fewout_kernel<CO, RR>), grid, block, 0, s, a.x.p, a.x.bs, a.wt, a.Mpad, a.bias, res, \
                      a.r.bs, a.y.p, a.y.bs, a.Cin, H, W, lx_log2, tiles_x, n_tasks)

@@ -149,7 +149,7 @@ def to_uint8_image(restored: torch.Tensor, h: int, w: int) -> torch.Tensor:
 
 
 def restore_image(net, img: torch.Tensor, factor: int = 8, crop_size: int = None, overlap_size: int = None,
-                  tile_batch: int = 16, square_multiple: int = None, carry_cache: bool = False) -> torch.Tensor:
+                  tile_batch: int = 32, square_multiple: int = None, carry_cache: bool = False) -> torch.Tensor:
     """One image through a test script's loop body (test_rain100L.py:147-190): pad, restore (whole
     image, or `crop_size` tiles with `overlap_size` overlap as the FPro / GoPro branches do),
     unpad, clamp.  img: [B,3,h,w] float32 on the GPU; returns [B,3,h,w].  With `square_multiple` the image
