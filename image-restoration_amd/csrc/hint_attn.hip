@@ -1044,7 +1044,9 @@ static int stats_splits(int tiles, int B, int P) {
   const int want = (1024 + tiles * tiles * B - 1) / (tiles * tiles * B);
   // more slabs cost the reduction kernel time in proportion to splits * B: allow many only while
   // the batch is small
-  const int cap = std::min(256, std::max(32, 512 / (tiles * tiles * B)));
+  // (a single large image, e.g. 1280 x 720: 512 slabs, so that every CU holds two workgroups as it does in a batch;
+  // measured slower for 256 x 256 and 640 x 360 planes, where the slab reduction grows by what the statistics gain)
+  const int cap = std::min(chunks >= 16384 ? 512 : 256, std::max(32, 512 / (tiles * tiles * B)));
   // a workgroup is latency-bound per chunk (one workgroup per CU, register double buffer only), so a
   // small problem is cut down to 2 chunks (64 px) per split: measured faster than 4 or 8 at B = 1
   return std::min(cap, std::max(1, std::min(want, chunks / 2)));
