@@ -607,8 +607,12 @@ static void launch_reduce_slabs(float* qk_part, double* gram_part, double* qsum_
   if (splits <= 1) return;
   const long n = (long)C * C + C;
   // (32 threads per element, 8 elements per workgroup, was measured slower at 256 slabs: 32-byte segments)
-  hipLaunchKernelGGL(reduce_slabs_kernel<8>, dim3((unsigned)((n + 31) / 32), std::max(B, G)), dim3(256), 0, s,
-                     qk_part, gram_part, qsum_part, q2_part, k2_part, C, splits, B, G);
+  if (splits <= 16)   // large batches: few slabs, many images - two threads per element, 128 elements per workgroup
+    hipLaunchKernelGGL(reduce_slabs_kernel<2>, dim3((unsigned)((n + 127) / 128), std::max(B, G)), dim3(256), 0, s,
+                       qk_part, gram_part, qsum_part, q2_part, k2_part, C, splits, B, G);
+  else
+    hipLaunchKernelGGL(reduce_slabs_kernel<8>, dim3((unsigned)((n + 31) / 32), std::max(B, G)), dim3(256), 0, s,
+                       qk_part, gram_part, qsum_part, q2_part, k2_part, C, splits, B, G);
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
@@ -1046,7 +1050,7 @@ static int stats_splits(int tiles, int B, int P) {
   // the batch is small
   // (a single large image, e.g. 1280 x 720: 512 slabs, so that every CU holds two workgroups as it does in a batch;
   // measured slower for 256 x 256 and 640 x 360 planes, where the slab reduction grows by what the statistics gain)
-  const int cap = std::min(chunks >= 16384 ? 512 : 256, std::max(32, 512 / (tiles * tiles * B)));
+  const int cap = std::min(chunks >= 16384 ? 512 : 256, std::max(16, 512 / (tiles * tiles * B)));
   // a workgroup is latency-bound per chunk (one workgroup per CU, register double buffer only), so a
   // small problem is cut down to 2 chunks (64 px) per split: measured faster than 4 or 8 at B = 1
   return std::min(cap, std::max(1, std::min(want, chunks / 2)));
