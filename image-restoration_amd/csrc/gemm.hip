@@ -1470,7 +1470,9 @@ static void launch_xs_bn(const GemmArgs& a, int loader, bool vec, hipStream_t s)
   const int n_mt = (a.M + 31) / 32;
   constexpr int TN = BN / 32;
   // (the attention * V epilogue is register-heavy: four accumulator tiles would spill)
-  if ((n_mt % 4 == 0 || n_mt >= 12) && loader != LD_GATHER)
+  // (nine row tiles, M = 288: four-column items 3 / 2 / 2 / 2 over the waves beat two-column items 5 / 5 / 4 / 4,
+  //  106 against 102 TFLOP/s - a weight fragment then feeds four MFMAs; at six row tiles the two-column form wins)
+  if ((n_mt % 4 == 0 || n_mt >= 9) && loader != LD_GATHER)
     launch_xs<BN, TN>(a, loader, vec, s);
   else if ((n_mt * 2) % 4 == 0 || n_mt * 2 >= 12)
     launch_xs<BN, TN / 2>(a, loader, vec, s);
