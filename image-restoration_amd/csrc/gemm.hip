@@ -1639,10 +1639,19 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   if (forced == 1) return launch_tile<2, 2, 2, 2>(a, loader, vec, s);
   if (forced == 2) return launch_tile<2, 2, 1, 2>(a, loader, vec, s);
   if (forced == 3) return launch_tile<2, 2, 1, 1>(a, loader, vec, s);
-  if (a.K >= 192 && (a.M >= 768 || a.K >= 1024) && a.M >= 384 && blocks(128, 128) >= 512)
+  // (per-shape sweep of the four tiles at B = 32, TFLOP/s as 96x128 / 128x128 / 64x128 / 64x64:
+  //  1x1 M384 K1021 P1024 90 / 112 / 107 / 103, M384 K384 81 / 99 / 96 / 93, M192 K510 P4096 88 / 84 / 105 / 100,
+  //  M192 K192 72 / 69 / 90 / 86, attention * V M192 K192 29 / 30 / 58 / 53 and M384 K384 40 / 45 / 71 / 69,
+  //  3x3 M96 K1728 P4096 54 / 68 / 59 / 62,
+  //  3x3 M192 K864 P16384 80 / 72 / 81 / 84)
+  if (a.K >= 192 && a.M >= 384 && blocks(128, 128) >= 512 && (loader != LD_GATHER || a.M >= 768))
+    launch_tile<2, 2, 2, 2>(a, loader, vec, s);
+  else if (loader == LD_CONV3 && a.K >= 1024 && a.M >= 96 && blocks(128, 128) >= 1024)
     launch_tile<2, 2, 2, 2>(a, loader, vec, s);
   else if (padded(96) < padded(64) && a.K > 128 && blocks(96, 128) >= 512)
     launch_tile<3, 1, 1, 4>(a, loader, vec, s);
+  else if (loader != LD_CONV3 && a.K >= 192 && a.M >= 128 && blocks(64, 128) >= 1024)
+    launch_tile<2, 2, 1, 2>(a, loader, vec, s);
   else
     launch_tile<2, 2, 1, 1>(a, loader, vec, s);
 }
