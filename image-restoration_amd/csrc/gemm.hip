@@ -1646,7 +1646,7 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   //  3x3 M192 K864 P16384 80 / 72 / 81 / 84)
   if (a.K >= 192 && a.M >= 384 && blocks(128, 128) >= 512 && (loader != LD_GATHER || a.M >= 768))
     launch_tile<2, 2, 2, 2>(a, loader, vec, s);
-  else if (loader == LD_CONV3 && a.K >= 1024 && a.M >= 96 && blocks(128, 128) >= 1024)
+  else if (loader == LD_CONV3 && a.K >= 1024 && a.M >= 96 && blocks(128, 128) >= 512)
     launch_tile<2, 2, 2, 2>(a, loader, vec, s);
   else if (padded(96) < padded(64) && a.K > 128 && blocks(96, 128) >= 512)
     launch_tile<3, 1, 1, 4>(a, loader, vec, s);
