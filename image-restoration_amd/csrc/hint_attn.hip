@@ -1150,7 +1150,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
   }
   JIRF_HIP_CHECK(hipGetLastError());
   {
-    Scope scope("hint_regroup_rows", 3.0 * C * (double)C * sh.splits * B,
+    Scope scope(intern_label("hint_regroup_rows C%d", C), 3.0 * C * (double)C * sh.splits * B,
                 (double)C * C * sh.splits * (4.0 * B + 8.0 * G), s);
     const size_t smem = 2 * (size_t)C * sizeof(double);
     launch_reduce_slabs(sc.qk_part, sc.gram_part, sc.qsum_part, q2_part, k2_part, C, sh.splits, B, G, s);
@@ -1230,7 +1230,7 @@ void launch_hint_attention(const HintAttnShape& sh, TV q, TV k, const HintAttnWe
     cu.C = C; cu.ipg = ipg;
     for (int i = 0; i < 4; ++i) { cu.gsz[i] = sh.gsz[i]; cu.goff[i] = sh.goff[i]; }
     cu.att_nat = sc.att_nat; cu.pooled = pooled; cu.cache_out = cache_out;
-    Scope scope("hint_cache_update", 40.0 * G * (double)C * C, 12.0 * G * (double)C * C, s);
+    Scope scope(intern_label("hint_cache_update C%d", C), 40.0 * G * (double)C * C, 12.0 * G * (double)C * C, s);
     hipLaunchKernelGGL(cache_update_kernel, dim3((C * C + 255) / 256, G), dim3(256), 0, s, cu);
     JIRF_HIP_CHECK(hipGetLastError());
   }
