@@ -1232,8 +1232,10 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void gemm_ws_kernel(const GemmArg
   __syncthreads();
 
   // a wave's pixel groups: g = first, first + stride, ...  (64 pixels each, never across images)
+  // With fewer groups than waves (a single 256 x 256 image has 1024) wave w of workgroup b starts at group
+  // w * gridDim.x + b, so that every CU still gets its share, on one wave per SIMD.
   const int stride = (int)gridDim.x * WS_WAVES;
-  int g = (int)blockIdx.x * WS_WAVES + wave;
+  int g = total_groups >= stride ? (int)blockIdx.x * WS_WAVES + wave : wave * (int)gridDim.x + (int)blockIdx.x;
   if (g >= total_groups) return;
   const int row2 = 2 * P * 4;                   // bytes per k-step (two activation rows)
   // one descriptor per image: rows past K read as zero (range check), pixels past P belong to discarded columns
@@ -1333,7 +1335,11 @@ static bool try_launch_ws(const GemmArgs& a, int loader, bool vec, hipStream_t s
   const long total = (long)groups_per_img * a.B;
   // enough pixel groups that every wave gets one or two: the prefetch window then pays for itself
   // (3600 groups, a 640 x 360 plane: 86 against 75 TFLOP/s on the K-loop kernel)
-  if (total < 256L * WS_WAVES * 3 / 2) return false;
+  // enough pixel groups that every wave gets one or two: the prefetch window then pays for itself (3600 groups, a
+  // 640 x 360 plane: 86 against 75 TFLOP/s on the K-loop kernel); from one group per SIMD on when the reduction is
+  // long enough to amortise the weight load (1024 groups, a single 256 x 256 image: M96 K255 72 against 63 TFLOP/s,
+  // M96 K96 35 against 41)
+  if (total < 256L * WS_WAVES * 3 / 2 && !(total >= 256L * 4 && a.K >= 192)) return false;
   const int grid = 256;
 #define JIRF_WS_CASE(N, E)                                                                               \
   do {                                                                                                   \
