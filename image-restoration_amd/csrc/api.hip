@@ -53,6 +53,17 @@ const Net* get(const jirf_net* n) {
 
 }  // namespace
 
+namespace jirf {
+// att[b][m][k] = att_t[b][k][m]: the block-diagonal attention of the GEMM weight layout back in natural orientation
+__global__ __launch_bounds__(256) void att_t_to_natural_kernel(const float* __restrict__ att_t, float* __restrict__ att,
+                                                               int C, int kpad, int mpad) {
+  const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (e >= C * C) return;
+  const int m = e / C, k = e - m * C;
+  att[(long)b * C * C + e] = att_t[((long)b * kpad + k) * mpad + m];
+}
+}  // namespace jirf
+
 extern "C" {
 
 int jirf_abi_version(void) { return JIRF_ABI_VERSION; }
@@ -548,6 +559,45 @@ int jirf_op_hint_attention_core(const float* qkv, const float* params_host, cons
     g.rq = sc.rq; g.rk = sc.rk;
     launch_gemm(g, LD_GATHER, s);
     JIRF_HIP_CHECK(hipMemcpyAsync(att, sc.att_nat, (size_t)B * C * C * 4, hipMemcpyDeviceToDevice, s));
+    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_head_attention_core(const float* qkv, const float* temperature_host, const float* ca_w_host,
+                                const float* ca_b_host, float norm_add_eps, float* out, float* att, int B, int C,
+                                int P, int heads, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(qkv && temperature_host && out && att, JIRF_EINVAL, "head_attention_core: null argument");
+    JIRF_REQUIRE(B > 0 && C > 0 && P >= 2 && heads > 0 && C % heads == 0, JIRF_EINVAL, "head_attention_core: bad shape");
+    JIRF_REQUIRE(ca_w_host || !ca_b_host, JIRF_EINVAL, "head_attention_core: att_ca bias without weight");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ch = C / heads;
+    WeightPool pool;
+    const float* temperature = pool.upload(temperature_host, (size_t)heads);
+    const float* ca_w = ca_w_host ? pool.upload(ca_w_host, (size_t)2 * ch * ch) : nullptr;
+    const float* ca_b = ca_b_host ? pool.upload(ca_b_host, (size_t)2 * ch) : nullptr;
+    HeadAttnScratch sc;
+    const int splits = head_attn_splits(B, C, P);
+    DeviceBuffer scratch;
+    scratch.ensure(head_attn_scratch_carve(B, C, P, splits, nullptr, &sc));
+    head_attn_scratch_carve(B, C, P, splits, scratch.p, &sc);
+    const TV t = tv(const_cast<float*>(qkv), 3L * C * P);
+    launch_head_attention(B, C, P, heads, tv_chan(t, 0, P), tv_chan(t, C, P), temperature, ca_w, ca_b, sc, s,
+                          norm_add_eps);
+    GemmArgs g{};
+    g.B = B; g.M = C; g.K = C; g.P = P;
+    g.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
+    const int kpad = (C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+    g.wt = sc.att_t;
+    g.wt_bs = (long)kpad * g.Mpad;
+    g.x = tv_chan(t, 2 * C, P); g.y = tv(out, (long)C * P);
+    g.epi = EP_STORE; g.imgs_per_group = 1;
+    launch_gemm(g, LD_PLAIN, s);
+    // the attention in natural orientation: att[b][m][k] = att_t[b][k][m]
+    hipLaunchKernelGGL(att_t_to_natural_kernel, dim3((unsigned)((C * C + 255) / 256), (unsigned)B), dim3(256), 0, s,
+                       sc.att_t, att, C, kpad, g.Mpad);
+    JIRF_HIP_CHECK(hipGetLastError());
     JIRF_HIP_CHECK(hipStreamSynchronize(s));
     return JIRF_OK;
   });

@@ -178,6 +178,18 @@ int jirf_op_hint_attention_core(const float* qkv, const float* params_host, cons
                                 float* cache_out, int B, int C, int P, int batch_mode,
                                 void* stream);
 
+/* Head-wise channel attention core of ASTv2 (Attention.execute astv2_arch.py:158-206 without the two
+ * convolutions around it: L2-normalised q, k over H W, (q k^T) * temperature[head], softmax branch, the
+ * relu^2 -> gelu sparse branch through att_ca (a 1x1 convolution over the ROW axis, weight [2 ch, ch],
+ * optional bias [2 ch]), attn0 * (1 + scale) + shift, attention * v) and, with ca_w_host == NULL, of FPro's
+ * MDTA (Attention.execute fpro_arch.py:128-144: softmax only).  qkv [B,3C,P] device; writes out [B,C,P]
+ * and att [B,C,C] (block-diagonal: head h occupies rows and columns h ch .. (h + 1) ch - 1, zero elsewhere).
+ * temperature_host [heads].  norm_add_eps > 0 selects FPro's patched normalize x / (||x|| + eps)
+ * (fpro_arch.py:10-12), 0 the x / sqrt(max(sum x^2, tiny)) form. */
+int jirf_op_head_attention_core(const float* qkv, const float* temperature_host, const float* ca_w_host,
+                                const float* ca_b_host, float norm_add_eps, float* out, float* att, int B, int C,
+                                int P, int heads, void* stream);
+
 /* ---- script-level image plumbing of the test scripts, on the device (all pointers are device
  *      pointers except the start lists; index / byte work, bit-exact) --------------------------- */
 

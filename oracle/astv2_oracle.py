@@ -65,27 +65,36 @@ def feed_forward(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
     return conv1x1(x1 * t[:, half:], p[pre + ".project_out.weight"], p.get(pre + ".project_out.bias"))
 
 
-def attention(p: Params, pre: str, x: torch.Tensor, heads: int, tap: Tap = None) -> torch.Tensor:
-    """Attention.execute (:158-206)."""
-    b, c, h, w = x.shape
-    ch, L = c // heads, h * w
-    qkv = conv3x3(conv1x1(x, p[pre + ".qkv.weight"], p.get(pre + ".qkv.bias")),
-                  p[pre + ".qkv_dwconv.weight"], p.get(pre + ".qkv_dwconv.bias"), groups=3 * c)
-    q, k, v = [t.reshape(b, heads, ch, L) for t in qkv.split(c, dim=1)]
+def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, temperature: torch.Tensor,
+                   ca_w: torch.Tensor, ca_b: Optional[torch.Tensor], heads: int):
+    """The part of Attention.execute between the two convolutions (:170-202).  q, k, v [b, C, L];
+    returns (attn [b, heads, ch, ch], out [b, C, L])."""
+    b, c, L = q.shape
+    ch = c // heads
+    q, k, v = [t.reshape(b, heads, ch, L) for t in (q, k, v)]
     q, k = l2_normalize_rows(q), l2_normalize_rows(k)
-    attn = (q @ k.transpose(-2, -1)) * p[pre + ".temperature"].reshape(1, heads, 1, 1)
+    attn = (q @ k.transpose(-2, -1)) * temperature.reshape(1, heads, 1, 1)
     attn0 = attn.softmax(dim=-1)
     attn1 = torch.relu(attn) ** 2
     attn1 = gelu(attn1) * attn1                                   # [b, head, ch(row), ch(col)]
     # att_ca is a 1x1 Conv2d over the ROW axis: the tensor is viewed as (N=b, C=ch_row, H=head, W=ch_col)
-    z = conv1x1(attn1.permute(0, 2, 1, 3), p[pre + ".att_ca.weight"], p.get(pre + ".att_ca.bias"))
+    z = conv1x1(attn1.permute(0, 2, 1, 3), ca_w, ca_b)
     z = z.permute(0, 2, 3, 1)                                     # [b, head, ch_col, 2ch]
     scale, shift = z[..., :ch], z[..., ch:]
     attn = attn0 * (1 + scale) + shift                            # positional: scale[r, c] = Z[c-th out][r-th col]
+    return attn, (attn @ v).reshape(b, c, L)
+
+
+def attention(p: Params, pre: str, x: torch.Tensor, heads: int, tap: Tap = None) -> torch.Tensor:
+    """Attention.execute (:158-206)."""
+    b, c, h, w = x.shape
+    qkv = conv3x3(conv1x1(x, p[pre + ".qkv.weight"], p.get(pre + ".qkv.bias")),
+                  p[pre + ".qkv_dwconv.weight"], p.get(pre + ".qkv_dwconv.bias"), groups=3 * c)
+    q, k, v = [t.reshape(b, c, h * w) for t in qkv.split(c, dim=1)]
+    attn, out = attention_core(q, k, v, p[pre + ".temperature"], p[pre + ".att_ca.weight"], p.get(pre + ".att_ca.bias"), heads)
     if tap:
         tap(pre + ".attn", attn.clone())
-    out = (attn @ v).reshape(b, c, h, w)
-    return conv1x1(out, p[pre + ".project_out.weight"], p.get(pre + ".project_out.bias"))
+    return conv1x1(out.reshape(b, c, h, w), p[pre + ".project_out.weight"], p.get(pre + ".project_out.bias"))
 
 
 def transformer_block(p: Params, pre: str, x, heads: int, is_att: bool, wb: bool, tap: Tap = None):

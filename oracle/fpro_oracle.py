@@ -68,17 +68,25 @@ def feed_forward(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
     return conv1x1(gelu(x1) * x2, p[pre + ".project_out.weight"], p.get(pre + ".project_out.bias"))
 
 
+def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, temperature: torch.Tensor, heads: int):
+    """MDTA between the two convolutions (:134-142).  q, k, v [b, C, L]; returns (attn [b, heads, ch, ch] after the
+    softmax, out [b, C, L])."""
+    b, c, L = q.shape
+    ch = c // heads
+    q, k, v = [t.reshape(b, heads, ch, L) for t in (q, k, v)]
+    q, k = normalize_rows(q), normalize_rows(k)
+    attn = ((q @ k.transpose(-2, -1)) * temperature.reshape(1, heads, 1, 1)).softmax(dim=-1)
+    return attn, (attn @ v).reshape(b, c, L)
+
+
 def attention(p: Params, pre: str, x: torch.Tensor, heads: int) -> torch.Tensor:
     """Attention.execute (:128-144): MDTA."""
     b, c, h, w = x.shape
-    ch, L = c // heads, h * w
     qkv = conv3x3(conv1x1(x, p[pre + ".qkv.weight"], p.get(pre + ".qkv.bias")),
                   p[pre + ".qkv_dwconv.weight"], p.get(pre + ".qkv_dwconv.bias"), groups=3 * c)
-    q, k, v = [t.reshape(b, heads, ch, L) for t in qkv.split(c, dim=1)]
-    q, k = normalize_rows(q), normalize_rows(k)
-    attn = (q @ k.transpose(-2, -1)) * p[pre + ".temperature"].reshape(1, heads, 1, 1)
-    out = (attn.softmax(dim=-1) @ v).reshape(b, c, h, w)
-    return conv1x1(out, p[pre + ".project_out.weight"], p.get(pre + ".project_out.bias"))
+    q, k, v = [t.reshape(b, c, h * w) for t in qkv.split(c, dim=1)]
+    _, out = attention_core(q, k, v, p[pre + ".temperature"], heads)
+    return conv1x1(out.reshape(b, c, h, w), p[pre + ".project_out.weight"], p.get(pre + ".project_out.bias"))
 
 
 def transformer_block(p: Params, pre: str, x, heads: int, is_att: bool, wb: bool):

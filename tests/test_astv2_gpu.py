@@ -64,3 +64,49 @@ def test_rejects_bad_shapes():
     net = _build(SMALL, make_astv2_state(SMALL, seed=1))
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 30, 32).cuda())
+
+
+@pytest.mark.parametrize("B,C,heads,P,bias,mdta", [
+    (1, 96, 2, 64 * 64, False, False),     # decoder_level1 / refinement of the shipped config: 48 channels per head
+    (2, 192, 8, 24 * 40, True, False),     # decoder_level3: 24 channels per head, with the att_ca bias
+    (1, 96, 4, 1000, False, False),        # decoder_level2; pixel count not a multiple of the staging chunk
+    (2, 96, 2, 48 * 48, False, True),      # FPro's MDTA: softmax only, x / (|x| + 1e-12) rows
+    (1, 192, 4, 32 * 32, False, True),
+])
+def test_head_attention_core(B, C, heads, P, bias, mdta):
+    """The head-wise channel attention between its two convolutions, at kernel level: statistics (split-K Q K^T,
+    row norms), the per-head kernel (softmax branch, relu^2 -> gelu branch through att_ca over the ROW axis,
+    scale / shift), attention * V.  ASTv2: astv2_arch.py:170-202; FPro (mdta): fpro_arch.py:134-142."""
+    from oracle import fpro_oracle as fo
+    from tests.gpu_util import call, dev, hptr, ptr, stream
+    rng = np.random.default_rng(C + heads + P)
+    ch = C // heads
+    # q and k rows share a few components, so that the normalised products spread over (-1, 1) and the attention
+    # is far from uniform
+    comp = rng.standard_normal((B, 4, P)).astype(np.float32)
+    load = rng.standard_normal((2 * C, 4)).astype(np.float32)
+    qkv = (0.3 * rng.standard_normal((B, 3 * C, P))).astype(np.float32)
+    qkv[:, :2 * C] += np.einsum("cr,brp->bcp", load, comp).astype(np.float32)
+    temp = (1.0 + 0.5 * rng.standard_normal(heads)).astype(np.float32) * 4.0
+    ca_w = (rng.standard_normal((2 * ch, ch)) / np.sqrt(ch)).astype(np.float32)
+    ca_b = (0.1 * rng.standard_normal(2 * ch)).astype(np.float32) if bias else None
+    q, k, v = [torch.from_numpy(qkv[:, i * C:(i + 1) * C]) for i in range(3)]
+    if mdta:
+        att_ref, out_ref = fo.attention_core(q, k, v, torch.from_numpy(temp), heads)
+    else:
+        att_ref, out_ref = ao.attention_core(q, k, v, torch.from_numpy(temp), torch.from_numpy(ca_w).reshape(2 * ch, ch, 1, 1),
+                                             None if ca_b is None else torch.from_numpy(ca_b), heads)
+    out = torch.empty(B, C, P, device="cuda")
+    att = torch.full((B, C, C), 7.0, device="cuda")
+    qd = dev(qkv)
+    call("jirf_op_head_attention_core", ptr(qd), hptr(temp), None if mdta else hptr(ca_w),
+         None if (mdta or ca_b is None) else hptr(ca_b), 1e-12 if mdta else 0.0, ptr(out), ptr(att), B, C, P, heads, stream())
+    a = att.cpu().numpy()
+    mag = max(1.0, float(att_ref.abs().max()))
+    for h in range(heads):
+        blk = a[:, h * ch:(h + 1) * ch, h * ch:(h + 1) * ch]
+        assert max_abs(blk, att_ref[:, h].numpy()) < 1e-5 * mag
+        a[:, h * ch:(h + 1) * ch, h * ch:(h + 1) * ch] = 0.0
+    assert float(np.abs(a).max()) == 0.0, "attention outside the head blocks must be zero"
+    assert max_abs(out.cpu().numpy(), out_ref.numpy()) < 2e-5 * max(1.0, float(out_ref.abs().max()))
+    assert float(att_ref.std()) > 0.2 / ch, "test did not drive the attention off uniform"
