@@ -603,4 +603,17 @@ int jirf_op_head_attention_core(const float* qkv, const float* temperature_host,
   });
 }
 
+int jirf_op_cross_window_attention(const float* q, const float* kv, float* out, int B, int C, int heads, int H,
+                                   int W, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(q && kv && out, JIRF_EINVAL, "cross_window_attention: null argument");
+    JIRF_REQUIRE(B > 0 && C > 0 && heads > 0, JIRF_EINVAL, "cross_window_attention: bad shape");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long P = (long)H * W;
+    launch_cross_window_attention(tv(const_cast<float*>(q), C * P), tv(const_cast<float*>(kv), 2L * C * P),
+                                  tv(out, C * P), B, C, heads, H, W, s);
+    return JIRF_OK;
+  });
+}
+
 }  // extern "C"

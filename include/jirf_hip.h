@@ -190,6 +190,14 @@ int jirf_op_head_attention_core(const float* qkv, const float* temperature_host,
                                 const float* ca_b_host, float norm_add_eps, float* out, float* att, int B, int C,
                                 int P, int heads, void* stream);
 
+/* 8x8-window cross attention of FPro's highFrequencyPromptFusion (fpro_arch.py:309-333) between its
+ * projections: q [B,C,H,W] (the feature after to_q, unscaled), kv [B,2C,H,W] (the prompt after to_kv: k in the
+ * first C channels, v in the rest), channel = head * (C / heads) + d.  Per window and head:
+ * softmax((q * d^-0.5) k^T) v, then the reference's transpose to [.., d, N] followed by a RESHAPE to [N, C]
+ * (:331-332), written back in window order: out [B,C,H,W] is what project_out consumes.  H, W multiples of 8. */
+int jirf_op_cross_window_attention(const float* q, const float* kv, float* out, int B, int C, int heads, int H,
+                                   int W, void* stream);
+
 /* ---- script-level image plumbing of the test scripts, on the device (all pointers are device
  *      pointers except the start lists; index / byte work, bit-exact) --------------------------- */
 

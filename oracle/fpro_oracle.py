@@ -156,24 +156,30 @@ def window_reverse(w: torch.Tensor, win: int, H: int, W: int) -> torch.Tensor:
     return w.reshape(B, H // win, W // win, win, win, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
 
 
+def cross_window_core(q: torch.Tensor, kv: torch.Tensor, heads: int) -> torch.Tensor:
+    """:322-332 — q [B_, N, C] (after to_q), kv [B_, N, 2C] (after to_kv) per window -> [B_, N, C]: softmax attention
+    per head, the product transposed to [.., d, N] and then RESHAPED (not permuted back) to [B_, N, C]."""
+    B_, N, c = q.shape
+    hd = c // heads
+    q = q.reshape(B_, N, 1, heads, hd).permute(2, 0, 3, 1, 4)[0] * (hd ** -0.5)
+    kv = kv.reshape(B_, N, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    k, v = kv[0], kv[1]
+    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    return (attn @ v).transpose(-2, -1).reshape(B_, N, c)         # the literal flatten of :331-332
+
+
 def high_fusion(p: Params, pre: str, feat: torch.Tensor, kvf: torch.Tensor) -> torch.Tensor:
     """highFrequencyPromptFusion.execute (:309-336): 8x8-window cross attention, q from the feature,
     k / v from the (depthwise-convolved) prompt; the product is transposed to [.., d, N] and then
     RESHAPED (not permuted back) to [B_, N, C] (:331-332)."""
     b, c, h, w = feat.shape
     c2 = kvf.shape[1]
-    heads, hd = PROMPT_HEADS, c // PROMPT_HEADS
     kvf = conv3x3(kvf, p[pre + ".kv_dwconv.weight"], p.get(pre + ".kv_dwconv.bias"), groups=c2)
     qw = window_partition(feat.permute(0, 2, 3, 1), WIN).reshape(-1, WIN * WIN, c)
     kw = window_partition(kvf.permute(0, 2, 3, 1), WIN).reshape(-1, WIN * WIN, c2)
-    B_, N, _ = qw.shape
     q = F.linear(qw, p[pre + ".to_q.to_q.weight"], p.get(pre + ".to_q.to_q.bias"))
-    q = q.reshape(B_, N, 1, heads, hd).permute(2, 0, 3, 1, 4)[0] * (hd ** -0.5)
     kv = F.linear(kw, p[pre + ".to_kv.to_kv.weight"], p.get(pre + ".to_kv.to_kv.bias"))
-    kv = kv.reshape(B_, N, 2, heads, hd).permute(2, 0, 3, 1, 4)
-    k, v = kv[0], kv[1]
-    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
-    out = (attn @ v).transpose(-2, -1).reshape(B_, N, c)          # the literal flatten of :331-332
+    out = cross_window_core(q, kv, PROMPT_HEADS)
     out = F.linear(out, p[pre + ".project_out.weight"], p[pre + ".project_out.bias"])
     out = window_reverse(out.reshape(-1, WIN, WIN, c), WIN, h, w)
     return out.permute(0, 3, 1, 2).contiguous()

@@ -93,3 +93,33 @@ def test_sots_sized_image_through_the_tiled_script_path():
     # tiles run 8 at a time here and one at a time there: the split-K schedule of the channel
     # attention depends on the batch, so sums differ in their last bits
     assert max_abs(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,heads,H,W", [
+    (1, 96, 2, 64, 64),      # the prompt modules after decoder_level2 / 1 / refinement: 48 channels per head (matrix-core kernel)
+    (2, 192, 2, 16, 24),     # after decoder_level3: 96 channels per head (the vector kernel)
+    (1, 64, 2, 8, 40),       # 32 channels per head, one row of windows
+])
+def test_cross_window_attention(B, C, heads, H, W):
+    """highFrequencyPromptFusion's 8x8-window cross attention at kernel level, including the reference's
+    transpose-then-reshape flatten (fpro_arch.py:322-332)."""
+    from tests.gpu_util import call, dev, ptr, stream
+    rng = np.random.default_rng(C + H)
+    q = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    kv = rng.standard_normal((B, 2 * C, H, W)).astype(np.float32)
+    qt = fo.window_partition(torch.from_numpy(q).permute(0, 2, 3, 1), fo.WIN).reshape(-1, 64, C)
+    kt = fo.window_partition(torch.from_numpy(kv).permute(0, 2, 3, 1), fo.WIN).reshape(-1, 64, 2 * C)
+    ref = fo.cross_window_core(qt, kt, heads)
+    ref = fo.window_reverse(ref.reshape(-1, fo.WIN, fo.WIN, C), fo.WIN, H, W).permute(0, 3, 1, 2).numpy()
+    out = torch.empty(B, C, H, W, device="cuda")
+    qd, kd = dev(q), dev(kv)
+    call("jirf_op_cross_window_attention", ptr(qd), ptr(kd), ptr(out), B, C, heads, H, W, stream())
+    assert max_abs(out.cpu().numpy(), ref) < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    # the flatten is not the plain one: a kernel that permuted the heads back would differ visibly
+    hd = C // heads
+    qh = qt.reshape(-1, 64, heads, hd).permute(0, 2, 1, 3) * hd ** -0.5
+    kh = kt[..., :C].reshape(-1, 64, heads, hd).permute(0, 2, 1, 3)
+    vh = kt[..., C:].reshape(-1, 64, heads, hd).permute(0, 2, 1, 3)
+    plain = ((qh @ kh.transpose(-2, -1)).softmax(-1) @ vh).permute(0, 2, 1, 3).reshape(-1, 64, C)
+    plain = fo.window_reverse(plain.reshape(-1, fo.WIN, fo.WIN, C), fo.WIN, H, W).permute(0, 3, 1, 2).numpy()
+    assert max_abs(plain, ref) > 0.1
