@@ -616,4 +616,32 @@ int jirf_op_cross_window_attention(const float* q, const float* kv, float* out, 
   });
 }
 
+int jirf_op_dynamic_filter(const float* x, const float* params_host, int groups, float* low, float* high, int B,
+                           int C, int H, int W, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && params_host && low && high, JIRF_EINVAL, "dynamic_filter: null argument");
+    JIRF_REQUIRE(B > 0 && groups > 0 && C % groups == 0 && H >= 2 && W >= 2, JIRF_EINVAL, "dynamic_filter: bad shape");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t F = (size_t)9 * groups;
+    WeightPool pool;
+    DynFilterW w{};
+    const float* p = params_host;
+    w.conv = pool.upload(p, F * C); p += F * C;
+    w.gate = pool.upload(p, F * F); p += F * F;
+    w.bn_w = pool.upload(p, F); p += F;
+    w.bn_b = pool.upload(p, F); p += F;
+    w.bn_mean = pool.upload(p, F); p += F;
+    w.bn_var = pool.upload(p, F);
+    w.groups = groups;
+    DeviceBuffer scratch;
+    scratch.ensure(((size_t)B * C + (size_t)B * F) * sizeof(float));
+    float* pooled = static_cast<float*>(scratch.p);
+    const long P = (long)H * W;
+    launch_dynfilter(tv(const_cast<float*>(x), C * P), w, pooled, pooled + (size_t)B * C, tv(low, C * P), tv(high, C * P),
+                     B, C, H, W, s);
+    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    return JIRF_OK;
+  });
+}
+
 }  // extern "C"

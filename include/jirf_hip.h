@@ -198,6 +198,14 @@ int jirf_op_head_attention_core(const float* qkv, const float* temperature_host,
 int jirf_op_cross_window_attention(const float* q, const float* kv, float* out, int B, int C, int heads, int H,
                                    int W, void* stream);
 
+/* FPro's frequency split, dynamic_filter_channel.execute (fpro_arch.py:355-375): global average pool ->
+ * 1x1 conv (C -> 9 groups) -> sigmoid gate -> BatchNorm (running statistics) -> softmax over the 9 taps per
+ * group -> per-image, per-group 3x3 low-pass with reflection padding; high = x - low.  x, low, high
+ * [B,C,H,W] device.  params_host: conv.weight [9 groups, C], conv_gate.weight [9 groups, 9 groups],
+ * bn.weight, bn.bias, bn.running_mean, bn.running_var [9 groups] each, concatenated (host). */
+int jirf_op_dynamic_filter(const float* x, const float* params_host, int groups, float* low, float* high, int B,
+                           int C, int H, int W, void* stream);
+
 /* ---- script-level image plumbing of the test scripts, on the device (all pointers are device
  *      pointers except the start lists; index / byte work, bit-exact) --------------------------- */
 

@@ -123,3 +123,31 @@ def test_cross_window_attention(B, C, heads, H, W):
     plain = ((qh @ kh.transpose(-2, -1)).softmax(-1) @ vh).permute(0, 2, 1, 3).reshape(-1, 64, C)
     plain = fo.window_reverse(plain.reshape(-1, fo.WIN, fo.WIN, C), fo.WIN, H, W).permute(0, 3, 1, 2).numpy()
     assert max_abs(plain, ref) > 0.1
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 48, 64, 64), (2, 48, 24, 40), (1, 16, 8, 12)])
+def test_dynamic_filter(B, C, H, W):
+    """dynamic_filter_channel (fpro_arch.py:355-375) at kernel level: the per-image 3x3 low-pass whose taps come
+    from the pooled image through conv / gate / BatchNorm / softmax, applied with reflection padding."""
+    from tests.gpu_util import call, dev, hptr, ptr, stream
+    rng = np.random.default_rng(C + H + W)
+    g = fo.FILTER_GROUPS
+    F9 = 9 * g
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32) + rng.standard_normal((B, C, 1, 1)).astype(np.float32)
+    prm = {"d.conv.weight": rng.standard_normal((F9, C, 1, 1)).astype(np.float32) * 0.5,
+           "d.conv_gate.weight": rng.standard_normal((F9, F9, 1, 1)).astype(np.float32) * 0.3,
+           "d.bn.weight": (1.0 + 0.3 * rng.standard_normal(F9)).astype(np.float32),
+           "d.bn.bias": (0.2 * rng.standard_normal(F9)).astype(np.float32),
+           "d.bn.running_mean": (0.1 * rng.standard_normal(F9)).astype(np.float32),
+           "d.bn.running_var": (0.5 + rng.random(F9)).astype(np.float32)}
+    low_ref, high_ref = fo.dynamic_filter({k: torch.from_numpy(v) for k, v in prm.items()}, "d", torch.from_numpy(x))
+    flat = np.concatenate([prm[k].ravel() for k in ("d.conv.weight", "d.conv_gate.weight", "d.bn.weight", "d.bn.bias",
+                                                    "d.bn.running_mean", "d.bn.running_var")]).astype(np.float32)
+    low = torch.empty(B, C, H, W, device="cuda")
+    high = torch.empty(B, C, H, W, device="cuda")
+    xd = dev(x)
+    call("jirf_op_dynamic_filter", ptr(xd), hptr(flat), g, ptr(low), ptr(high), B, C, H, W, stream())
+    assert max_abs(low.cpu().numpy(), low_ref.numpy()) < 1e-5 * max(1.0, float(low_ref.abs().max()))
+    assert max_abs(high.cpu().numpy(), high_ref.numpy()) < 1e-5 * max(1.0, float(high_ref.abs().max()))
+    # the filter differs from image to image and is not the identity
+    assert float(high_ref.abs().mean()) > 0.05
