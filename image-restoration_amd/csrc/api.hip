@@ -644,4 +644,26 @@ int jirf_op_dynamic_filter(const float* x, const float* params_host, int groups,
   });
 }
 
+int jirf_op_resize(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, int bicubic, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && y, JIRF_EINVAL, "resize: null argument");
+    JIRF_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, JIRF_EINVAL, "resize: bad shape");
+    launch_resize(x, (long)C * Hi * Wi, (long)Hi * Wi, y, (long)C * Ho * Wo, B, C, Hi, Wi, Ho, Wo, bicubic != 0,
+                  static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
+int jirf_op_fspg_high(const float* f, const float* k1, const float* b1, const float* k2, const float* b2,
+                      const float* wmap, float* y, int B, int C, int H, int W, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(f && k1 && b1 && k2 && b2 && wmap && y, JIRF_EINVAL, "fspg_high: null argument");
+    JIRF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, JIRF_EINVAL, "fspg_high: bad shape");
+    const long P = (long)H * W;
+    launch_fspg_high(tv(const_cast<float*>(f), C * P), k1, b1, k2, b2, wmap, tv(y, C * P), B, C, H, W,
+                     static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
 }  // extern "C"

@@ -104,6 +104,8 @@ SIGNATURES = {
     "jirf_op_head_attention_core": (_i, [_fp, _vp, _vp, _vp, C.c_float, _fp, _fp, _i, _i, _i, _i, _vp]),
     "jirf_op_cross_window_attention": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_dynamic_filter": (_i, [_fp, _vp, _i, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "jirf_op_resize": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "jirf_op_fspg_high": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
 }
 
 

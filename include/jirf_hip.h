@@ -206,6 +206,18 @@ int jirf_op_cross_window_attention(const float* q, const float* kv, float* out, 
 int jirf_op_dynamic_filter(const float* x, const float* params_host, int groups, float* low, float* high, int B,
                            int C, int H, int W, void* stream);
 
+/* nn.interpolate(x, size=(Ho, Wo), mode="bilinear" | "bicubic", align_corners=False) as FPro's prompt generator
+ * calls it (fpro_arch.py:405,414,425-436; half-pixel centres, edge clamp, bicubic with A = -0.75 as torch): x
+ * [B,C,Hi,Wi], y [B,C,Ho,Wo] device. */
+int jirf_op_resize(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, int bicubic, void* stream);
+
+/* The high-frequency prompt of frequenctSpecificPromptGenetator (fpro_arch.py:404-411) after its resizes: f
+ * [B,C,H,W] (the high part at the level's size), wmap [C,H,W] (the learned weight at that size), body.0
+ * (depthwise 1x3: k1 [C,3], b1 [C]) then body.1 (depthwise 3x1: k2 [C,3], b2 [C]), zero padded;
+ * y = gelu(body(f)) * f * wmap.  All pointers device. */
+int jirf_op_fspg_high(const float* f, const float* k1, const float* b1, const float* k2, const float* b2,
+                      const float* wmap, float* y, int B, int C, int H, int W, void* stream);
+
 /* ---- script-level image plumbing of the test scripts, on the device (all pointers are device
  *      pointers except the start lists; index / byte work, bit-exact) --------------------------- */
 

@@ -151,3 +151,43 @@ def test_dynamic_filter(B, C, H, W):
     assert max_abs(high.cpu().numpy(), high_ref.numpy()) < 1e-5 * max(1.0, float(high_ref.abs().max()))
     # the filter differs from image to image and is not the identity
     assert float(high_ref.abs().mean()) > 0.05
+
+
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo", [(64, 64, 32, 32), (64, 96, 16, 24), (128, 128, 64, 64), (32, 32, 64, 64),
+                                         (24, 40, 36, 52), (256, 256, 128, 128)])
+@pytest.mark.parametrize("bicubic", [0, 1])
+def test_resize(Hi, Wi, Ho, Wo, bicubic):
+    """The two interpolations of the prompt generator (fpro_arch.py:405,414,425-436) against torch's
+    F.interpolate(align_corners=False): bilinear for the high part and the learned maps, bicubic for the low part.
+    (That Jittor's bicubic equals torch's is one of the named, unverifiable assumptions of the oracle.)"""
+    import torch.nn.functional as F
+    from tests.gpu_util import call, dev, ptr, stream
+    rng = np.random.default_rng(Hi + Wo + bicubic)
+    x = rng.standard_normal((2, 5, Hi, Wi)).astype(np.float32)
+    ref = F.interpolate(torch.from_numpy(x), size=(Ho, Wo), mode="bicubic" if bicubic else "bilinear", align_corners=False)
+    y = torch.empty(2, 5, Ho, Wo, device="cuda")
+    xd = dev(x)
+    call("jirf_op_resize", ptr(xd), ptr(y), 2, 5, Hi, Wi, Ho, Wo, bicubic, stream())
+    assert max_abs(y.cpu().numpy(), ref.numpy()) < 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 48, 64, 64), (2, 48, 16, 24), (1, 8, 8, 8)])
+def test_high_frequency_prompt(B, C, H, W):
+    """frequenctSpecificPromptGenetator's high branch at kernel level (fpro_arch.py:404-411): depthwise 1x3, depthwise
+    3x1, GELU, times the input and the learned map (both given at the level's size, so the oracle's resizes are the
+    identity)."""
+    from tests.gpu_util import call, dev, ptr, stream
+    rng = np.random.default_rng(C + H)
+    f = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    prm = {"g.body.0.weight": rng.standard_normal((C, 1, 1, 3)).astype(np.float32) * 0.5,
+           "g.body.0.bias": (0.1 * rng.standard_normal(C)).astype(np.float32),
+           "g.body.1.weight": rng.standard_normal((C, 1, 3, 1)).astype(np.float32) * 0.5,
+           "g.body.1.bias": (0.1 * rng.standard_normal(C)).astype(np.float32),
+           "g.weight": rng.standard_normal((1, C, H, W)).astype(np.float32)}
+    ref = fo.fspg_high({k: torch.from_numpy(v) for k, v in prm.items()}, "g", torch.from_numpy(f), H, W)
+    y = torch.empty(B, C, H, W, device="cuda")
+    d = {k: dev(v) for k, v in prm.items()}
+    fd = dev(f)
+    call("jirf_op_fspg_high", ptr(fd), ptr(d["g.body.0.weight"]), ptr(d["g.body.0.bias"]), ptr(d["g.body.1.weight"]),
+         ptr(d["g.body.1.bias"]), ptr(d["g.weight"]), ptr(y), B, C, H, W, stream())
+    assert max_abs(y.cpu().numpy(), ref.numpy()) < 1e-5 * max(1.0, float(ref.abs().max()))
