@@ -1339,7 +1339,11 @@ static bool try_launch_ws(const GemmArgs& a, int loader, bool vec, hipStream_t s
   // 640 x 360 plane: 86 against 75 TFLOP/s on the K-loop kernel); from one group per SIMD on when the reduction is
   // long enough to amortise the weight load (1024 groups, a single 256 x 256 image: M96 K255 72 against 63 TFLOP/s,
   // M96 K96 35 against 41)
-  if (total < 256L * WS_WAVES * 3 / 2 && !(total >= 256L * 4 && a.K >= 192)) return false;
+  // (between those, e.g. 2501 groups of a 488 x 328 plane, some SIMDs get two groups and most one: the K-loop
+  // kernel's 96 x 128 tile wins there, 90 against 68 TFLOP/s at M96 K384)
+  const long simd_rounds = (total + 1023) / 1024;
+  const bool one_round = a.K >= 192 && total >= 1024 && (double)total >= 0.95 * 1024.0 * (double)simd_rounds && simd_rounds <= 2;
+  if (total < 256L * WS_WAVES * 3 / 2 && !one_round) return false;
   const int grid = 256;
 #define JIRF_WS_CASE(N, E)                                                                               \
   do {                                                                                                   \
@@ -1654,7 +1658,7 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
     launch_tile<2, 2, 2, 2>(a, loader, vec, s);
   else if (loader == LD_CONV3 && a.K >= 1024 && a.M >= 96 && blocks(128, 128) >= 512)
     launch_tile<2, 2, 2, 2>(a, loader, vec, s);
-  else if (padded(96) < padded(64) && a.K > 128 && blocks(96, 128) >= 512)
+  else if (padded(96) < padded(64) && (a.K > 128 || (a.K >= 96 && blocks(96, 128) >= 1024)) && blocks(96, 128) >= 512)
     launch_tile<3, 1, 1, 4>(a, loader, vec, s);
   else if (loader != LD_CONV3 && a.K >= 192 && a.M >= 128 && blocks(64, 128) >= 1024)
     launch_tile<2, 2, 1, 2>(a, loader, vec, s);
