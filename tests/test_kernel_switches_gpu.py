@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"JIRF_WINATTN_VALU": "1", "JIRF_CROSSWIN_VALU": "1"},   # vector-ALU window attention kernels
     {"JIRF_GEMM_NO_XS": "1"},                                 # every GEMM on the K-loop kernel
     {"JIRF_GEMM_TILE": "3"},                                  # ... with 64 x 64 tiles, no few-output conv kernel
+    {"JIRF_GEMM_TILE": "2"},                                  # ... 64 x 128 (the default only picks it at large batches)
+    {"JIRF_GEMM_TILE": "1"},                                  # ... 128 x 128
+    {"JIRF_GEMM_TILE": "0"},                                  # ... 96 x 128
     {"JIRF_GEMM_SPLIT_BF16": "1"},                            # split-bf16 activation-stationary GEMM
 ])
 def test_golden_cases_with_switches(switches):
