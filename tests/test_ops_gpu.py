@@ -31,6 +31,9 @@ def gemm_tol(k, mag=1.0):
     (2, 255, 96, 512 * 256 + 24),   # weight-stationary streaming kernel: 3 row tiles, odd K, a ragged last pixel group
     (4, 127, 48, 256 * 256),        # ... 2 row tiles (the second half empty), odd K
     (5, 96, 24, 240 * 256),         # ... 1 row tile, groups of one wave running into the next image
+    (1, 255, 96, 256 * 256),        # ... a single image: 1024 groups, one per SIMD, waves dealt across the workgroups
+    (1, 192, 96, 2000 * 64 + 8),    # ... 2001 groups: two rounds of one per SIMD, a ragged last group
+    (1, 384, 96, 488 * 328),        # 2501 groups: between the rounds, the K-loop kernel's 96 x 128 tile
 ])
 def test_conv1x1(B, Cin, Cout, P):
     x, w, b = rnd(B, Cin, P), rnd(Cout, Cin, scale=Cin ** -0.5), rnd(Cout)
