@@ -1662,6 +1662,13 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
     launch_tile<3, 1, 1, 4>(a, loader, vec, s);
   else if (loader != LD_CONV3 && a.K >= 192 && a.M >= 128 && blocks(64, 128) >= 1024)
     launch_tile<2, 2, 1, 2>(a, loader, vec, s);
+  // long reductions on small grids (the deep levels of a single image or of a training batch of two; split-K supplies
+  // the workgroups): wider tiles re-read the operands less - 1x1 M512 K4096 P1024 at B = 2 50 -> 84 TFLOP/s with
+  // 64 x 128, 3x3 M512 K2304 P1024 34 -> 54 with 128 x 128
+  else if (loader != LD_CONV3 && a.K >= 1024 && a.M >= 128 && a.P >= 1024)
+    launch_tile<2, 2, 1, 2>(a, loader, vec, s);
+  else if (loader == LD_CONV3 && a.K >= 2048 && a.M >= 256)
+    launch_tile<2, 2, 2, 2>(a, loader, vec, s);
   else
     launch_tile<2, 2, 1, 1>(a, loader, vec, s);
 }
