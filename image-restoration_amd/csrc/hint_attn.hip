@@ -1045,7 +1045,9 @@ __global__ __launch_bounds__(256) void cache_update_kernel(const CacheUpdArgs a)
 // enough workgroups to fill the chip, but at least 2 chunks (64 px) per split
 static int stats_splits(int tiles, int B, int P) {
   const int chunks = (P + ST_CH - 1) / ST_CH;
-  const int want = (1024 + tiles * tiles * B - 1) / (tiles * tiles * B);
+  // about 512 workgroups (one resident round of two per CU): a sweep over 128 ... 4096 at batches 1 to 32 had its
+  // minimum there (batch 32: statistics + reduction 12.3 ms per step against 12.6 at 1024 and 14.2 at 256)
+  const int want = (512 + tiles * tiles * B - 1) / (tiles * tiles * B);
   // more slabs cost the reduction kernel time in proportion to splits * B: allow many only while
   // the batch is small
   // (a single large image, e.g. 1280 x 720: 512 slabs, so that every CU holds two workgroups as it does in a batch;
