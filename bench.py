@@ -110,7 +110,7 @@ def _dominant(detail):
                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
 
 
-def run_extra_config(nets, arch, B, Hh, Ww, steps, warmup=2, crop=0, overlap=0, seed=7):
+def run_extra_config(nets, arch, B, Hh, Ww, steps, warmup=2, crop=0, overlap=0, seed=7, carry=False):
     """One more configuration of BASELINE.json on this GPU (N = 1 only): the same timing discipline as the
     headline (warm-up, K steps between synchronisations, inputs resident in HBM), then one pass with HIP
     events around every launch for the model FLOP rate and the dominant launch shape."""
@@ -133,7 +133,7 @@ def run_extra_config(nets, arch, B, Hh, Ww, steps, warmup=2, crop=0, overlap=0, 
         if arch == "HINT":
             net.qv_cache = None
         if crop:
-            return harness.restore_image(net, x, factor=8, crop_size=crop, overlap_size=overlap)
+            return harness.restore_image(net, x, factor=8, crop_size=crop, overlap_size=overlap, carry_cache=carry)
         if script:
             return harness.restore_image(net, x, factor=need, square_multiple=128 if arch == "AST" else None)
         return net(x)
@@ -147,6 +147,9 @@ def run_extra_config(nets, arch, B, Hh, Ww, steps, warmup=2, crop=0, overlap=0, 
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     assert bool(torch.isfinite(y).all()), "non-finite output"
+    if carry:
+        net.qv_cache = None
+        net.batch_mode = "per_image"
     nat = net.native()
     nat.enable_kernel_timing(True)
     detail, flops = {}, 0.0
@@ -159,7 +162,9 @@ def run_extra_config(nets, arch, B, Hh, Ww, steps, warmup=2, crop=0, overlap=0, 
         flops += k["flops"]
     nat.enable_kernel_timing(False)
     rec = {"arch": arch, "batch": B, "height": Hh, "width": Ww,
-           "path": (f"script loop body: reflect pad to x8, {crop}x{crop} tiles overlap {overlap}, mean blend, crop, clamp" if crop else
+           "path": (f"script loop body: reflect pad to x8, {crop}x{crop} tiles overlap {overlap}"
+                    + (", one B = 1 call per tile in list order with qv_cache carried from tile to tile "
+                       "(Motion_Deblurring/test_GoPro.py:142-171)" if carry else "") + ", mean blend, crop, clamp" if crop else
                     ("script loop body: reflect pad" + (" to the enclosing square (side % 128 == 0)" if arch == "AST" else f" to x{need}")
                      + ", forward, crop, clamp") if script else "forward"),
            "steps": steps, "ms_per_step": round(ms, 3), "ms_per_image": round(ms / B, 3),
@@ -233,14 +238,16 @@ def train_step_bench(args, rank, local_rank, world, use_dist):
         "loss_first": round(losses[0], 6), "loss_last": round(losses[-1], 6),
         "host_queueing_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
     }
-    if use_dist and world > 1:
-        # the exchange on its own: the same all-reduce, timed outside the step
+    if use_dist:
+        # the exchange on its own: the same all-reduce of the flat gradient buffer, timed outside the step (with one
+        # rank under the launcher RCCL still runs the collective on the device)
         sync_all()
         t1 = time.perf_counter()
         for _ in range(5):
             tr.average_gradients()
         sync_all()
         out["allreduce_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        out["allreduce_floats"] = tr.n_flat
     if rank == 0 and world == 1 and not args.no_roofline:
         tr.kernel_timing(True)
         acc, detail = {}, {}
@@ -293,6 +300,65 @@ def train_step_bench(args, rank, local_rank, world, use_dist):
     return out
 
 
+def images_bench(args, rank, local_rank, world, use_dist):
+    """BASELINE configs[2] / [3] as the scripts run them: a folder of --images equal-sized images restored by
+    `harness.restore_images` - image i on rank i % N, each through the loop body of the test scripts (reflect pad,
+    forward, crop, clamp), --batch of them in flight per call with per-image semantics, results gathered on rank 0.
+    The folder is fixed, so the work per GPU falls as N grows ("strong" scaling).  A step = the whole folder."""
+    import torch.distributed as dist
+    from jirf_hip import harness
+    from jirf_hip.synthetic import default_config, make_state, synthetic_images
+    from basicsr.models.archs import define_network
+    cfg = default_config(args.arch)
+    net = define_network(dict(cfg, type=args.arch))
+    net.load_state_dict(make_state(args.arch, cfg, seed=1))
+    net.cuda(local_rank).eval()
+    N, Hh, Ww = args.images, args.height or 321, args.width or 481
+    # image i is the same whatever the number of ranks; a rank uploads only the ones it will restore
+    mine = set(range(rank, N, world))
+    imgs = [torch.from_numpy(synthetic_images(1, Hh, Ww, seed=1000 + i, sigma=50 if args.arch == "HINT" else 0)[0]).cuda()
+            if i in mine else torch.empty(3, Hh, Ww) for i in range(N)]
+    kw = dict(batch=args.batch)
+    if args.crop_size:
+        kw.update(factor=8, crop_size=args.crop_size, overlap_size=args.overlap_size)
+    elif args.arch == "AST":
+        kw.update(square_multiple=128)
+    else:
+        kw.update(factor=8)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        harness.restore_images(net, imgs, **kw)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = harness.restore_images(net, imgs, **kw)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        assert len(got) == N and all(tuple(g.shape) == (3, Hh, Ww) and bool(torch.isfinite(g).all()) for g in got)
+    ms = elapsed / args.steps * 1e3
+    return {"metric": f"restored megapixels/sec (node), {args.arch} over a folder of {N} {Ww}x{Hh} images",
+            "value": round(N * Hh * Ww / 1e6 / (ms / 1e3), 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "ms_per_image": round(ms / N, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform [0,1) RGB images, seeded per image index; seeded random weights in the reference key layout)",
+            "config": {"workload": f"{args.arch} (reference default constructor) over {N} {Ww}x{Hh} RGB images, each through the "
+                                   "test scripts' loop body (reflect pad, forward, crop, clamp), fp32; results gathered on rank 0 "
+                                   "inside the timed region",
+                       "images": N, "height": Hh, "width": Ww, "batch_in_flight": args.batch,
+                       "sharding": "image i on rank i % N, weights replicated, no data-path collective; one gather of the results"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +381,9 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the `configs` array (the other shapes of the BASELINE metric, N = 1 only)")
     ap.add_argument("--detail", default=None, help="write the per-shape kernel table to this file")
+    ap.add_argument("--images", type=int, default=0,
+                    help="restore a fixed folder of this many --height x --width images (default 321 x 481), sharded by image "
+                         "over the ranks and gathered on rank 0 (BASELINE configs[2]); --batch of them in flight per call")
     ap.add_argument("--train-step", action="store_true",
                     help="time the AST data-parallel optimisation step instead of the inference forward")
     ap.add_argument("--train-batch", type=int, default=2, help="crops per GPU per optimisation step (--train-step)")
@@ -341,6 +410,15 @@ def main():
 
     if args.train_step:
         out = train_step_bench(args, rank, local_rank, world, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
+
+    if args.images:
+        out = images_bench(args, rank, local_rank, world, use_dist)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -473,13 +551,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra_configs and not args.host_io and \
             (args.arch, Hh, Ww, args.crop_size) == ("HINT", 256, 256, 0):
         nets = {"HINT": net}
-        extra = [("HINT", 16, 256, 256, 6, 0, 0), ("HINT", 1, 256, 256, 20, 0, 0), ("HINT", 1, 720, 1280, 4, 0, 0),
-                 ("AST", 16, 256, 256, 6, 0, 0), ("AST", 1, 256, 256, 20, 0, 0), ("AST", 1, 321, 481, 10, 0, 0),
-                 ("ASTv2", 1, 321, 481, 10, 0, 0), ("FPro", 1, 460, 620, 6, 256, 158)]
+        # (arch, batch, height, width, steps, tile, overlap, carried cache)
+        extra = [("HINT", 16, 256, 256, 6, 0, 0, False), ("HINT", 1, 256, 256, 20, 0, 0, False),
+                 ("HINT", 1, 720, 1280, 4, 0, 0, False), ("HINT", 1, 720, 1280, 2, 256, 200, True),
+                 ("AST", 16, 256, 256, 6, 0, 0, False), ("AST", 1, 256, 256, 20, 0, 0, False),
+                 ("AST", 1, 321, 481, 10, 0, 0, False), ("ASTv2", 1, 321, 481, 10, 0, 0, False),
+                 ("FPro", 1, 460, 620, 6, 256, 158, False)]
         out["configs"] = []
-        for a_, b_, h_, w_, k_, c_, o_ in extra:
-            out["configs"].append(run_extra_config(nets, a_, b_, h_, w_, k_, crop=c_, overlap=o_))
-            if a_ != "HINT" and a_ in nets and all(e[0] != a_ for e in extra[extra.index((a_, b_, h_, w_, k_, c_, o_)) + 1:]):
+        for a_, b_, h_, w_, k_, c_, o_, cc_ in extra:
+            out["configs"].append(run_extra_config(nets, a_, b_, h_, w_, k_, warmup=1 if cc_ else 2, crop=c_, overlap=o_,
+                                                   carry=cc_))
+            if a_ != "HINT" and a_ in nets and all(e[0] != a_ for e in extra[extra.index((a_, b_, h_, w_, k_, c_, o_, cc_)) + 1:]):
                 del nets[a_]            # free the arena before the next network plans its own
         net.batch_mode = "per_image"
         # the second half of BASELINE configs[4]: one AST optimisation step (forward, loss, backward, clip, Adam)

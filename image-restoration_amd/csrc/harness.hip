@@ -262,20 +262,25 @@ void launch_psnr_stats(const float* a, const float* b, int C, int H, int W, int 
 // _ssim_cly (cv2.filter2D, BORDER_REPLICATE) on the BT.601 luma.  Both are separable.  The pass over the colour
 // axis of a C-plane image with replicate padding is a C x C matrix (host-computed, `mix`), applied while the
 // tile is loaded; then 11 taps along x and 11 along y through LDS.  A workgroup owns a 32 x 32 tile of one output
-// plane: 42 x 42 inputs of the five quantities.  fp32 like the reference's convolution; the map is summed in
+// plane: 42 x 42 inputs of the five quantities.  The colour form computes in fp32 like the reference's convolution
+// (_ssim_3d runs on float32 variables); the luma form in double like _ssim_cly (:222-223 cast to float64 before
+// cv2.filter2D: on [0, 255] luma the sigma = E[x^2] - mu^2 step cancels about four digits, which fp32 does not
+// have to spare against C2 = 58.5), on 16 x 16 tiles so that the double images fit the LDS.  The map is summed in
 // double, per workgroup, and the partials are folded in index order (deterministic).
-constexpr int SSIM_T = 32, SSIM_R = 5, SSIM_IN = SSIM_T + 2 * SSIM_R;
+constexpr int SSIM_T = 32, SSIM_TD = 16, SSIM_R = 5;
 struct SsimArgs {
   int C, H, W, border, quantise, y_channel, blue_plane, planes_out;
-  float c1, c2;
-  float g[11];
+  double c1d, c2d;     // (0.01 max)^2, (0.03 max)^2: rounded to float first for the fp32 form
+  double gd[11];       // the window: float values for the fp32 form, doubles for the luma form
   float mix[4][4];
 };
 
+template <typename T, int SSIM_T>
 __global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                            const SsimArgs k, double* __restrict__ part) {
-  __shared__ float in[5][SSIM_IN][SSIM_IN + 1];
-  __shared__ float tmp[5][SSIM_IN][SSIM_T];
+  constexpr int SSIM_IN = SSIM_T + 2 * SSIM_R;
+  __shared__ T in[5][SSIM_IN][SSIM_IN + 1];
+  __shared__ T tmp[5][SSIM_IN][SSIM_T];
   __shared__ double red[256];
   const int h = k.H - 2 * k.border, w = k.W - 2 * k.border;
   const long plane = (long)k.H * k.W;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restri
     const int iy = e / SSIM_IN, ix = e - iy * SSIM_IN;
     const int yy = min(max(y0 + iy - SSIM_R, 0), h - 1), xx = min(max(x0 + ix - SSIM_R, 0), w - 1);
     const long at = (long)(yy + k.border) * k.W + xx + k.border;
-    float q[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    T q[5] = {0, 0, 0, 0, 0};
     if (k.y_channel) {
       double ya = 16.0, yb = 16.0;
       const double wgt[3] = {24.966, 128.553, 65.481};
@@ -295,7 +300,8 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restri
         ya += (double)(va / 255.0f) * wgt[c];
         yb += (double)(vb / 255.0f) * wgt[c];
       }
-      const float fa = (float)(ya / 255.0) * 255.0f, fb = (float)(yb / 255.0) * 255.0f;
+      // to_y_channel returns float32 luma; _ssim_cly widens it to float64 before anything is multiplied
+      const T fa = (T)((float)(ya / 255.0) * 255.0f), fb = (T)((float)(yb / 255.0) * 255.0f);
       q[0] = fa; q[1] = fb; q[2] = fa * fa; q[3] = fb * fb; q[4] = fa * fb;
     } else {
       for (int c = 0; c < k.C; ++c) {
@@ -303,8 +309,8 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restri
         if (m == 0.f) continue;
         float va = a[c * plane + at], vb = b[c * plane + at];
         if (k.quantise) { va = quantise_u8(va); vb = quantise_u8(vb); }
-        q[0] = fmaf(m, va, q[0]); q[1] = fmaf(m, vb, q[1]);
-        q[2] = fmaf(m, va * va, q[2]); q[3] = fmaf(m, vb * vb, q[3]); q[4] = fmaf(m, va * vb, q[4]);
+        q[0] += (T)(m * va); q[1] += (T)(m * vb);
+        q[2] += (T)(m * (va * va)); q[3] += (T)(m * (vb * vb)); q[4] += (T)(m * (va * vb));
       }
     }
 #pragma unroll
@@ -315,9 +321,9 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restri
     const int iy = e / SSIM_T, ox = e - iy * SSIM_T;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      float t = 0.f;
+      T t = 0;
 #pragma unroll
-      for (int u = 0; u < 11; ++u) t = fmaf(k.g[u], in[j][iy][ox + u], t);
+      for (int u = 0; u < 11; ++u) t += (T)k.gd[u] * in[j][iy][ox + u];
       tmp[j][iy][ox] = t;
     }
   }
@@ -326,18 +332,19 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const float* __restri
   for (int e = threadIdx.x; e < SSIM_T * SSIM_T; e += 256) {
     const int oy = e / SSIM_T, ox = e - oy * SSIM_T;
     if (y0 + oy >= h || x0 + ox >= w) continue;
-    float f[5];
+    T f[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      float t = 0.f;
+      T t = 0;
 #pragma unroll
-      for (int u = 0; u < 11; ++u) t = fmaf(k.g[u], tmp[j][oy + u][ox], t);
+      for (int u = 0; u < 11; ++u) t += (T)k.gd[u] * tmp[j][oy + u][ox];
       f[j] = t;
     }
-    const float mu1 = f[0], mu2 = f[1];
-    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float s1 = f[2] - mu1_sq, s2 = f[3] - mu2_sq, s12 = f[4] - mu12;
-    acc += (double)(((2.f * mu12 + k.c1) * (2.f * s12 + k.c2)) / ((mu1_sq + mu2_sq + k.c1) * (s1 + s2 + k.c2)));
+    const T c1 = (T)k.c1d, c2 = (T)k.c2d;
+    const T mu1 = f[0], mu2 = f[1];
+    const T mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const T s1 = f[2] - mu1_sq, s2 = f[3] - mu2_sq, s12 = f[4] - mu12;
+    acc += (double)((((T)2 * mu12 + c1) * ((T)2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2)));
   }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -357,7 +364,9 @@ __global__ __launch_bounds__(64) void ssim_final_kernel(double* __restrict__ wor
 }
 
 size_t ssim_work_doubles(int C, int H, int W) {
-  return 4 + (size_t)std::max(C, 1) * ((H + SSIM_T - 1) / SSIM_T) * ((W + SSIM_T - 1) / SSIM_T);
+  // enough for either tiling (the luma form has one output plane of 16 x 16 tiles)
+  return 4 + std::max((size_t)std::max(C, 1) * ((H + SSIM_T - 1) / SSIM_T) * ((W + SSIM_T - 1) / SSIM_T),
+                      (size_t)((H + SSIM_TD - 1) / SSIM_TD) * ((W + SSIM_TD - 1) / SSIM_TD));
 }
 
 void launch_ssim_stats(const float* a, const float* b, int C, int H, int W, int border, int quantise, int y_channel,
@@ -370,17 +379,26 @@ void launch_ssim_stats(const float* a, const float* b, int C, int H, int W, int 
   SsimArgs k{};
   k.C = C; k.H = H; k.W = W; k.border = border; k.quantise = quantise; k.y_channel = y_channel; k.blue_plane = blue_plane;
   k.planes_out = y_channel ? 1 : C;
-  k.c1 = (0.01f * max_value) * (0.01f * max_value);
-  k.c2 = (0.03f * max_value) * (0.03f * max_value);
+  if (y_channel) {
+    k.c1d = (0.01 * (double)max_value) * (0.01 * (double)max_value);
+    k.c2d = (0.03 * (double)max_value) * (0.03 * (double)max_value);
+  } else {
+    k.c1d = (double)((0.01f * max_value) * (0.01f * max_value));
+    k.c2d = (double)((0.03f * max_value) * (0.03f * max_value));
+  }
   // cv2.getGaussianKernel(11, 1.5): exp(-(i - 5)^2 / (2 sigma^2)), normalised to sum 1
   double g[11], gs = 0.0;
   for (int i = 0; i < 11; ++i) { g[i] = std::exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); gs += g[i]; }
-  for (int i = 0; i < 11; ++i) k.g[i] = (float)(g[i] / gs);
+  for (int i = 0; i < 11; ++i) k.gd[i] = y_channel ? g[i] / gs : (double)(float)(g[i] / gs);
   for (int co = 0; co < C; ++co)
     for (int t = 0; t < 11; ++t) k.mix[co][std::min(std::max(co + t - 5, 0), C - 1)] += (float)(g[t] / gs);
   const int h = H - 2 * border, w = W - 2 * border;
-  const dim3 grid((w + SSIM_T - 1) / SSIM_T, (h + SSIM_T - 1) / SSIM_T, k.planes_out);
-  hipLaunchKernelGGL(ssim_partial_kernel, grid, dim3(256), 0, s, a, b, k, work);
+  const int tile = y_channel ? SSIM_TD : SSIM_T;
+  const dim3 grid((w + tile - 1) / tile, (h + tile - 1) / tile, k.planes_out);
+  if (y_channel)
+    hipLaunchKernelGGL((ssim_partial_kernel<double, SSIM_TD>), grid, dim3(256), 0, s, a, b, k, work);
+  else
+    hipLaunchKernelGGL((ssim_partial_kernel<float, SSIM_T>), grid, dim3(256), 0, s, a, b, k, work);
   JIRF_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(64), 0, s, work, (long)grid.x * grid.y * grid.z,
                      (double)h * w * k.planes_out);

@@ -8,6 +8,7 @@
 // depthwise 3x3 of the FRFN token MLP.  Everything is fp32, planar [B][C][P] like the forward, and every
 // reduction is two-stage with a fixed order (no atomics), so a step is reproducible.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <memory>
 #include <mutex>
@@ -80,16 +81,19 @@ __global__ __launch_bounds__(64) void sum_parts_kernel(const double* __restrict_
 }
 
 // Gradient clip + Adam on flat buffers, Jittor's update (jt.optim.Adam.step):
+//   g <- grad_scale * g                                            (the 1 / ranks of the data-parallel mean; 1: off)
 //   g <- g * min(max_norm / (||g|| + 1e-6), 1)                     (Optimizer.clip_grad_norm; max_norm <= 0: off)
 //   m <- b0 m + (1 - b0) g ;  v <- b1 v + (1 - b1) g^2
 //   p <- p - m * lr * sqrt(1 - b1^t) / (1 - b0^t) / (sqrt(v) + eps)      (eps outside the bias correction)
 // torch_form != 0 selects torch's placement instead: p <- p - lr / (1 - b0^t) * m / (sqrt(v) / sqrt(1 - b1^t) + eps).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
-                                                   const double* __restrict__ sumsq, float max_norm, float lr, float b0,
-                                                   float b1, float eps, float bc0, float bc1, int torch_form) {
-  float clip = 1.0f;
-  if (max_norm > 0.f && sumsq) clip = fminf(max_norm / ((float)sqrt(sumsq[0]) + 1e-6f), 1.0f);
+                                                   const double* __restrict__ sumsq, float max_norm, float grad_scale,
+                                                   float lr, float b0, float b1, float eps, float bc0, float bc1,
+                                                   int torch_form) {
+  // sumsq is the sum of squares of the buffer as it stands, i.e. before grad_scale: ||grad_scale g|| = grad_scale ||g||
+  float clip = grad_scale;
+  if (max_norm > 0.f && sumsq) clip *= fminf(max_norm / (grad_scale * (float)sqrt(sumsq[0]) + 1e-6f), 1.0f);
   const float step = lr * sqrtf(bc1) / bc0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * clip;
@@ -1182,7 +1186,10 @@ int guarded_t(F&& f) {
 // training calls on one device share it and order their use through the stream: calls that overlap on one
 // device (two streams, two threads) race.
 enum { SC_PACK = 0, SC_PART_A = 1, SC_PART_B = 2, SC_SMALL = 3, SC_SPLITK = 4, SC_SLOTS = 5 };
-void* train_scratch(int slot, size_t bytes) {
+// Counts the reallocations of any scratch buffer of any device: a captured step holds the addresses it was recorded
+// with, so a holder compares this number before every replay (jirf_train_scratch_generation).
+std::atomic<long> g_scratch_generation{0};
+void* train_scratch(int slot, size_t bytes, hipStream_t stream) {
   static std::mutex mu;
   static DeviceBuffer pool[64][SC_SLOTS];
   int dev = 0;
@@ -1191,8 +1198,19 @@ void* train_scratch(int slot, size_t bytes) {
   std::lock_guard<std::mutex> lock(mu);
   DeviceBuffer& b = pool[dev][slot];
   if (b.bytes < bytes) {
+    // Growing means a device synchronisation and a free / allocate pair, none of which a stream capture allows:
+    // refuse before touching anything, so that the capture ends with a clear error and the buffers stay valid.
+    hipStreamCaptureMode relaxed = hipStreamCaptureModeRelaxed;
+    JIRF_HIP_CHECK(hipThreadExchangeStreamCaptureMode(&relaxed));      // the query itself must not break a capture
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const hipError_t qe = hipStreamIsCapturing(stream, &st);
+    JIRF_HIP_CHECK(hipThreadExchangeStreamCaptureMode(&relaxed));
+    JIRF_REQUIRE(qe != hipSuccess || st == hipStreamCaptureStatusNone, JIRF_ESTATE,
+                 "training scratch slot %d would have to grow to %zu bytes inside a stream capture: run one step at "
+                 "this shape outside the capture first", slot, bytes);
     JIRF_HIP_CHECK(hipDeviceSynchronize());   // the old buffer may still be in use by queued kernels
     b.ensure(bytes + bytes / 4);
+    g_scratch_generation.fetch_add(1);
   }
   return b.p;
 }
@@ -1234,8 +1252,8 @@ void dw_shared_launch(const float* dy, long dy_bs, const float* x, long x_bs, fl
   slabs = (int)std::max<long>(1, std::min<long>(chunks / 8, (1024 + tm * tk - 1) / (tm * tk)));
   const int cps = (int)((chunks + slabs - 1) / slabs);
   slabs = (int)((chunks + cps - 1) / cps);
-  part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float)));
-  dbpart = want_db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double))) : nullptr;
+  part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float), s));
+  dbpart = want_db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double), s)) : nullptr;
   hipLaunchKernelGGL((dw_shared_kernel<CONV, WM, WK, TI, TJ>), dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs,
                      part, dbpart, B, M, K, P, cps, cg);
 }
@@ -1271,8 +1289,8 @@ void conv_dw_launch(const float* dy, long dy_bs, const float* x, long x_bs, floa
     slabs = (int)std::max<long>(1, std::min<long>(chunks / 16, (2048 + tm * tk - 1) / (tm * tk)));
     const int cps = (int)((chunks + slabs - 1) / slabs);
     slabs = (int)((chunks + cps - 1) / cps);
-    part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float)));
-    dbpart = db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double))) : nullptr;
+    part = static_cast<float*>(train_scratch(SC_PART_A, (size_t)slabs * M * K * sizeof(float), s));
+    dbpart = db ? static_cast<double*>(train_scratch(SC_PART_B, (size_t)slabs * M * sizeof(double), s)) : nullptr;
     if (cg)
       hipLaunchKernelGGL(linear_dw_kernel<true>, dim3(tm, tk, slabs), dim3(256), 0, s, dy, dy_bs, x, x_bs, part, dbpart,
                          B, M, K, P, cps, geom);
@@ -1296,6 +1314,8 @@ void conv_dw_launch(const float* dy, long dy_bs, const float* x, long x_bs, floa
 using namespace jirf;
 
 extern "C" {
+
+long jirf_train_scratch_generation(void) { return g_scratch_generation.load(); }
 
 int jirf_train_kernel_timing(int enable) {
   return guarded_t([&] {
@@ -1331,7 +1351,7 @@ int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, lo
     JIRF_REQUIRE(pred && target && n > 0 && (loss_dev || loss_host), JIRF_EINVAL, "smooth_l1: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<long>(1024, (n + 255) / 256);
-    double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double)));
+    double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double), s));
     {
       Scope sc("train_smooth_l1", 6.0 * n, 12.0 * n, s);
       hipLaunchKernelGGL(smooth_l1_kernel, dim3(blocks), dim3(256), 0, s, pred, target, grad, n,
@@ -1353,7 +1373,7 @@ int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, 
     JIRF_REQUIRE(x && n > 0 && (out_dev || out_host), JIRF_EINVAL, "sumsq: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<long>(1024, (n + 255) / 256);
-    double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double)));
+    double* pd = static_cast<double*>(train_scratch(SC_SMALL, (size_t)(blocks + 1) * sizeof(double), s));
     {
       Scope sc("train_grad_sumsq", 2.0 * n, 4.0 * n, s);
       hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, pd);
@@ -1370,15 +1390,16 @@ int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, 
 }
 
 int jirf_train_adam_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq_dev, float max_norm,
-                         float lr, float beta0, float beta1, float eps, int step, int torch_form, void* stream) {
+                         float grad_scale, float lr, float beta0, float beta1, float eps, int step, int torch_form,
+                         void* stream) {
   return guarded_t([&] {
-    JIRF_REQUIRE(p && g && m && v && n > 0 && step >= 1, JIRF_EINVAL, "adam_step: bad arguments");
+    JIRF_REQUIRE(p && g && m && v && n > 0 && step >= 1 && grad_scale > 0.f, JIRF_EINVAL, "adam_step: bad arguments");
     JIRF_REQUIRE(max_norm <= 0.f || sumsq_dev, JIRF_EINVAL, "adam_step: clipping needs the gradient's sum of squares");
     const float bc0 = 1.0f - std::pow(beta0, (float)step), bc1 = 1.0f - std::pow(beta1, (float)step);
     const int blocks = (int)std::min<long>(4096, (n + 255) / 256);
     Scope sc("train_adam", 12.0 * n, 28.0 * n, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
-                       sumsq_dev, max_norm, lr, beta0, beta1, eps, bc0, bc1, torch_form);
+                       sumsq_dev, max_norm, grad_scale, lr, beta0, beta1, eps, bc0, bc1, torch_form);
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });
@@ -1433,7 +1454,7 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
       // sits behind the matrix
       if (bias && w_kind == JIRF_W_DECONV) bias_use = w + (size_t)Kp * Mp;
     } else {
-      float* wp = static_cast<float*>(train_scratch(SC_PACK, (size_t)pg.floats() * sizeof(float)));
+      float* wp = static_cast<float*>(train_scratch(SC_PACK, (size_t)pg.floats() * sizeof(float), s));
       {
         Scope sc(intern_label("train_pack_weights K%d M%d", g.K, M), 0.0, 4.0 * ((double)Kp * Mp + (double)g.K * M), s);
         hipLaunchKernelGGL(pack_train_kernel, dim3((unsigned)(((long)Kp * Mp + 255) / 256)), dim3(256), 0, s, w, wp,
@@ -1449,7 +1470,7 @@ int jirf_train_conv(const float* x, long x_bs, const float* w, int w_kind, const
     }
     g.M = M; g.Mpad = Mp; g.wt = wt; g.bias = bias_use;
     // slabs of the split-K form (deep levels: long reductions over a handful of pixels)
-    g.splitk_ws = static_cast<float*>(train_scratch(SC_SPLITK, SPLITK_WS_FLOATS * sizeof(float)));
+    g.splitk_ws = static_cast<float*>(train_scratch(SC_SPLITK, SPLITK_WS_FLOATS * sizeof(float), s));
     g.splitk_floats = SPLITK_WS_FLOATS;
     const long Pin = (long)Hin * Win;
     const long Pout = (g.epi == EP_SHUFFLE) ? 4L * g.P : g.P;
@@ -1573,8 +1594,8 @@ int jirf_train_layernorm_bwd(const float* x, long x_bs, const float* dy, long dy
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = (P + 63) / 64;
     const int slots = gx * B;
-    double* pw = static_cast<double*>(train_scratch(SC_PART_A, (size_t)slots * C * sizeof(double)));
-    double* pb = static_cast<double*>(train_scratch(SC_PART_B, (size_t)slots * C * sizeof(double)));
+    double* pw = static_cast<double*>(train_scratch(SC_PART_A, (size_t)slots * C * sizeof(double), s));
+    double* pb = static_cast<double*>(train_scratch(SC_PART_B, (size_t)slots * C * sizeof(double), s));
     Scope sc(intern_label("train_layernorm_bwd C%d P%d", C, P), 12.0 * B * C * (double)P,
              4.0 * B * C * (double)P * (add ? 4 : 3), s);
     if (slots < 512)
@@ -1678,7 +1699,7 @@ int jirf_train_dwconv3x3(const float* x, long x_bs, const float* w, const float*
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float* wu = w;
     if (flip) {
-      float* wf = static_cast<float*>(train_scratch(SC_SMALL, (size_t)C * 9 * sizeof(float)));
+      float* wf = static_cast<float*>(train_scratch(SC_SMALL, (size_t)C * 9 * sizeof(float), s));
       hipLaunchKernelGGL(flip9_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, w, wf, C);
       JIRF_HIP_CHECK(hipGetLastError());
       wu = wf;
@@ -1697,7 +1718,7 @@ int jirf_train_dwconv3x3_bwd_weight(const float* x, long x_bs, const float* dy, 
     const long P = (long)H * W;
     // row slabs of at least 4096 pixels per workgroup (a thread's fp32 sums stay short), enough workgroups to fill the chip
     const int slabs = (int)std::max<long>(1, std::min<long>(std::min<long>(P / 4096, H), std::max<long>((4096 + (long)B * C - 1) / ((long)B * C), P / 65536)));
-    double* part = static_cast<double*>(train_scratch(SC_PART_A, (size_t)B * slabs * C * 10 * sizeof(double)));
+    double* part = static_cast<double*>(train_scratch(SC_PART_A, (size_t)B * slabs * C * 10 * sizeof(double), s));
     Scope sc(intern_label("train_dwconv_dw C%d H%d W%d", C, H, W), 20.0 * B * C * (double)P, 8.0 * B * C * (double)P, s);
     hipLaunchKernelGGL(dwconv_dw_kernel, dim3(C, B * slabs), dim3(256), 0, s, x, dense(x_bs, C, P), dy, dense(dy_bs, C, P),
                        part, C, H, W, slabs);
@@ -1743,8 +1764,8 @@ int jirf_train_window_attention_bwd(const float* qkv, long qkv_bs, const float* 
     a.q = qkv; a.k = qkv + (long)C * P; a.v = qkv + 2L * C * P; a.dout = dout;
     a.dq = dqkv; a.dk = dqkv + (long)C * P; a.dv = dqkv + 2L * C * P;
     a.table = table; a.w2 = w2;
-    a.part_table = static_cast<double*>(train_scratch(SC_PART_A, (size_t)heads * a.chunks * 225 * sizeof(double)));
-    a.part_w = static_cast<double*>(train_scratch(SC_PART_B, ((size_t)heads * a.chunks * 2 + 2) * sizeof(double)));
+    a.part_table = static_cast<double*>(train_scratch(SC_PART_A, (size_t)heads * a.chunks * 225 * sizeof(double), s));
+    a.part_w = static_cast<double*>(train_scratch(SC_PART_B, ((size_t)heads * a.chunks * 2 + 2) * sizeof(double), s));
     double* gsum = a.part_w + (size_t)heads * a.chunks * 2;
     Scope sc(intern_label("train_win_attn_bwd C%d H%d W%d", C, H, W), 10.0 * 64 * C * (double)P * B, 28.0 * C * (double)P * B, s);
     hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(a.chunks, heads), dim3(64), 0, s, a);

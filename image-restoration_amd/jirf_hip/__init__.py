@@ -60,13 +60,14 @@ SIGNATURES = {
     "jirf_op_conv1x1": (_i, [_fp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "jirf_op_ln_conv1x1": (_i, [_fp, _fp, _fp, _i, _vp, _fp, _i, _i, _i, _i, _vp]),
     "jirf_op_ln_conv1x1_static": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "jirf_train_scratch_generation": (_l, []),
     "jirf_train_kernel_timing": (_i, [_i]),
     "jirf_train_kernel_times": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(_i), _i, C.POINTER(_i)]),
     "jirf_train_smooth_l1": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, _fp, C.POINTER(C.c_double), _vp]),
     "jirf_train_sumsq": (_i, [_fp, C.c_long, _vp, C.POINTER(C.c_double), _vp]),
     "jirf_train_adam_step": (_i, [_fp, _fp, _fp, _fp, C.c_long, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
-                                  C.c_float, _i, _i, _vp]),
+                                  C.c_float, C.c_float, _i, _i, _vp]),
     "jirf_train_conv": (_i, [_fp, _l, _fp, _i, _fp, _fp, _l, _fp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_train_conv_bwd_weight": (_i, [_fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_train_linear_bwd_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),

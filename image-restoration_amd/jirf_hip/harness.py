@@ -202,3 +202,50 @@ def restore_image(net, img: torch.Tensor, factor: int = 8, crop_size: int = None
         done.stacked = torch.cat(outs, dim=0)
         restored = mergeimage(done, starts, crop_size, tuple(xp.shape))
     return crop_clamp(restored, h, w)
+
+
+def restore_images(net, images: Sequence[torch.Tensor], batch: int = 8, balance: bool = False, gather: bool = True,
+                   dst: int = 0, group=None, **restore_kwargs):
+    """The scripts' loop over a folder of images (Deraining/test_rain100L.py:141-190), spread over the ranks of a
+    process group: every rank passes the same list of [3,h,w] / [1,3,h,w] float32 images (host or device), image i
+    is restored by rank i % ranks (balance=True: by pixel count, for folders of mixed sizes) on that rank's GPU
+    through `restore_image(net, ..., **restore_kwargs)`, and rank `dst` receives the restored images in list order
+    (the other ranks None; gather=False: every rank keeps its {index: image}).  Consecutive images of one shape on a
+    rank go through the network `batch` at a time with per-image batch semantics - each is still its own B = 1
+    call of the reference - and a network that carries state between calls (HINT's qv_cache) starts every call cold,
+    so the result does not depend on the number of ranks or on `batch`.  Weights are replicated; nothing but the
+    final gather crosses ranks."""
+    from . import sharding
+    dev = getattr(net, "_device", None)
+    device = torch.device("cuda", torch.cuda.current_device() if dev is None else dev)
+    stateful = hasattr(net, "qv_cache")
+
+    def shape_of(t):
+        return tuple(t.shape[-3:])
+
+    def run(indices: List[int], mine: list) -> list:
+        out: List[torch.Tensor] = []
+        had_mode = getattr(net, "batch_mode", None)
+        try:
+            if had_mode is not None:
+                net.batch_mode = "per_image"
+            i = 0
+            while i < len(mine):
+                j = i + 1
+                while j < len(mine) and j - i < batch and shape_of(mine[j]) == shape_of(mine[i]):
+                    j += 1
+                x = torch.stack([t.reshape(shape_of(t)) for t in mine[i:j]]).to(device, torch.float32)
+                if stateful:
+                    net.qv_cache = None
+                y = restore_image(net, x, **restore_kwargs)
+                out.extend(y[k] for k in range(j - i))
+                i = j
+            if stateful:
+                net.qv_cache = None
+        finally:
+            if had_mode is not None:
+                net.batch_mode = had_mode
+        return out
+
+    costs = [float(t.shape[-1] * t.shape[-2]) for t in images] if balance else None
+    return sharding.run_sharded(list(images), run, costs=costs, gather=gather, dst=dst, group=group)

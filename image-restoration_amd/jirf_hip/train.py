@@ -58,18 +58,26 @@ def _vp(a: Optional[int]):
     return a
 
 
-def average_flat_gradients(g: torch.Tensor, group=None) -> None:
-    """The data-parallel exchange of the step: one all-reduce (sum) of the flat gradient buffer over the ranks of
-    `group`, then the division by their number - the mean that Jittor's optimizer takes under MPI.  In place; a
-    no-op without an initialised process group or with a single rank.  Works on any device the backend of the
-    group serves (RCCL for GPU tensors, gloo for CPU tensors)."""
+def allreduce_flat_gradients(g: torch.Tensor, group=None) -> float:
+    """The data-parallel exchange of the step: ONE all-reduce (sum) of the flat gradient buffer over the ranks of
+    `group`, in place.  Returns 1 / ranks, the factor that turns the sum into the mean Jittor's optimizer takes under
+    MPI; the training step hands it to the clip + Adam kernel (`grad_scale` of jirf_train_adam_step) instead of
+    spending a pass over the buffer on it.  With an initialised process group the collective runs whatever the
+    number of ranks - a one-rank launch under the launcher exercises the same RCCL call as eight - and without one
+    nothing happens and the factor is 1.  Works on any device the group's backend serves (RCCL for GPU tensors,
+    gloo for CPU tensors)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return
-    world = dist.get_world_size(group)
-    if world > 1:
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-        g.mul_(1.0 / world)
+        return 1.0
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / dist.get_world_size(group)
+
+
+def average_flat_gradients(g: torch.Tensor, group=None) -> None:
+    """allreduce_flat_gradients followed by the division, for callers that want the mean in the buffer itself."""
+    scale = allreduce_flat_gradients(g, group)
+    if scale != 1.0:
+        g.mul_(scale)
 
 
 def broadcast_flat_parameters(p: torch.Tensor, group=None, src: int = 0) -> None:
@@ -112,7 +120,9 @@ class AstTrainStep:
         self.coupled = 1 if coupled else 0
         self.torch_form = 0 if adam_form == "jittor" else 1
         self.group = process_group
-        self.iteration = 0
+        self.iteration = 0        # the caller's current_iter: decides the clip (image_restoration_model.py:269)
+        self.opt_step = 0         # the optimiser's own count of updates (jt.optim.Adam's n_step): bias correction
+        self._grad_scale = 1.0    # 1 / ranks after the all-reduce of this step's gradient
         self.E = int(cfg.get("embed_dim", 32))
         self.depths = list(cfg.get("depths", [2] * 9))
         self.heads = list(cfg.get("num_heads", [1, 2, 4, 8, 16, 16, 8, 4, 2]))
@@ -149,6 +159,8 @@ class AstTrainStep:
         # use_graph: optimize_parameters replays forward + backward as one captured hipGraph (from the second step on)
         self.use_graph = bool(use_graph)
         self._graph, self._graph_key, self._graph_in, self._graph_out = None, None, None, None
+        self._graph_generation = -1
+        self._eager_shapes = set()       # input shapes that have run a step outside a capture (scratch is sized)
         self._timing = False
         self.last_loss = None
         self._loss_ring = torch.zeros(64, dtype=torch.float64, device=self.device)
@@ -483,6 +495,8 @@ class AstTrainStep:
         lq = lq.to(self.device, torch.float32)
         gt = gt.to(self.device, torch.float32)
         key = tuple(lq.shape)
+        if self._graph is not None and self._graph_generation != self.L.jirf_train_scratch_generation():
+            self._graph = None                            # some scratch buffer moved: the recorded addresses are stale
         if self._graph is None or self._graph_key != key:
             self._graph = None
             self._graph_in = (torch.empty_like(lq, memory_format=torch.contiguous_format),
@@ -500,6 +514,7 @@ class AstTrainStep:
                 finally:
                     self._stream = None
             self._graph, self._graph_key, self._graph_out = graph, key, out
+            self._graph_generation = self.L.jirf_train_scratch_generation()
         self._graph_in[0].copy_(lq)
         self._graph_in[1].copy_(gt)
         self._draw_scales(key[0])
@@ -624,7 +639,8 @@ class AstTrainStep:
 
     # ---- the step (image_restoration_model.py:235-276) -------------------------------------------------------------
     def average_gradients(self) -> None:
-        average_flat_gradients(self.g, self.group)
+        """The all-reduce (sum) of the gradient buffer; the division by the number of ranks rides in the update."""
+        self._grad_scale = allreduce_flat_gradients(self.g, self.group)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         broadcast_flat_parameters(self.p, self.group, src)
@@ -648,12 +664,30 @@ class AstTrainStep:
         """clip_grad_norm(0.01) when enabled and past the first iteration (image_restoration_model.py:269-270), then
         Adam (optimizer_g.step())."""
         clip = self.use_grad_clip and self.iteration > 1
+        self.opt_step += 1
         if clip:
             check(self.L.jirf_train_sumsq(_vp(self.g.data_ptr()), self.n_flat, _vp(self._sumsq.data_ptr()), None, self._s()))
         check(self.L.jirf_train_adam_step(_vp(self.p.data_ptr()), _vp(self.g.data_ptr()), _vp(self.m.data_ptr()),
                                           _vp(self.v.data_ptr()), self.n_flat, _vp(self._sumsq.data_ptr()) if clip else None,
-                                          self.max_norm if clip else 0.0, self.lr, self.betas[0], self.betas[1], self.eps,
-                                          self.iteration, self.torch_form, self._s()))
+                                          self.max_norm if clip else 0.0, self._grad_scale, self.lr, self.betas[0],
+                                          self.betas[1], self.eps, self.opt_step, self.torch_form, self._s()))
+        self._grad_scale = 1.0
+
+    def optimizer_state_dict(self) -> dict:
+        """What a resume needs beside the weights: both Adam moments (per parameter, the state-dict layout) and the
+        optimiser's step count (the reference pickles the optimizer object, base_model.py:260-285)."""
+        return {"step": self.opt_step, "m": self._unflatten(self.m), "v": self._unflatten(self.v)}
+
+    def load_optimizer_state_dict(self, state: dict) -> None:
+        for name, flat in (("m", self.m), ("v", self.v)):
+            host = np.zeros(self.n_flat, dtype=np.float32)
+            for k, shp in self.specs.items():
+                a = np.asarray(state[name][k], dtype=np.float32)
+                if tuple(a.shape) != tuple(shp):
+                    raise ValueError(f"{name}[{k}]: shape {a.shape}, expected {shp}")
+                host[self.offset[k]: self.offset[k] + a.size] = a.reshape(-1)
+            flat.copy_(torch.from_numpy(host))
+        self.opt_step = int(state["step"])
 
     def optimize_parameters(self, lq: torch.Tensor, gt: torch.Tensor, current_iter: Optional[int] = None,
                             sync_loss: bool = True):
@@ -662,11 +696,23 @@ class AstTrainStep:
         next 64 steps) - the reference's loss is a lazy Jittor variable too, evaluated when the logger prints it.
         `log_loss` is the mean over the ranks (reduce_loss_dict), of the same kind."""
         self.iteration = int(current_iter) if current_iter is not None else self.iteration + 1
-        if self.use_graph and self._plan is not None and self.drop_scales is None and not self._timing:
-            loss_t, pred = self._captured_forward_backward(lq, gt)
-        else:
+        # a shape is captured only after a step at that shape has run outside a capture: that step grows the
+        # library's scratch buffers to what the shape needs, which a capture cannot do
+        shape = tuple(lq.shape)
+        loss_t = None
+        if self.use_graph and self._plan is not None and self.drop_scales is None and not self._timing and \
+                shape in self._eager_shapes:
+            try:
+                loss_t, pred = self._captured_forward_backward(lq, gt)
+            except jirf_hip.JirfError:
+                # the capture was refused (scratch would have had to grow): this step runs kernel by kernel, which
+                # sizes the buffers, and the next one captures again
+                self._graph, self._stream = None, None
+                torch.cuda.synchronize(self.device)
+        if loss_t is None:
             self.g.zero_()
             loss_t, pred = self.forward_backward(lq, gt, sync_loss=False)
+            self._eager_shapes.add(shape)
         self.output = pred
         self.average_gradients()
         self.apply_update()

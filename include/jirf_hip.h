@@ -146,7 +146,10 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
  * jirf_op_ln_conv1x1: w_dev [Cout,Cin] is a DEVICE array in the reference layout (packed by a kernel
  * inside the call).  Limits: ceil16(Cin) * ceil128(Cout) <= JIRF_STATIC_MAX_PACKED_WEIGHT_FLOATS and
  * B * P <= JIRF_STATIC_MAX_PIXELS, otherwise JIRF_EINVAL and nothing is launched.  All calls on one
- * GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+ * GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+ * Under stream capture: make ONE call on the device outside any capture first.  The first call on a
+ * device looks the array's address up (hipGetSymbolAddress, which may load the code object) and sets a
+ * kernel attribute once; neither belongs inside a capture.  Every later call only queues kernels. */
 #define JIRF_STATIC_MAX_PACKED_WEIGHT_FLOATS (512 * 1024)
 #define JIRF_STATIC_MAX_PIXELS (1024 * 1024)
 int jirf_op_ln_conv1x1_static(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
@@ -274,6 +277,12 @@ int jirf_op_ssim_stats(const float* a, const float* b, int C, int H, int W, int 
  *      process ends): training calls that overlap on one device race.  Every reduction has a fixed order (no
  *      atomics): a step is reproducible. */
 
+/* Number of times any training scratch buffer of any device has been reallocated since the library was loaded.  A
+ * caller that replays a captured step (hipGraph) records it at capture and must capture again once it has changed:
+ * the recorded kernels hold the old addresses.  A call that would have to grow a buffer while its stream is being
+ * captured fails with JIRF_ESTATE and leaves every buffer as it was.  No counterpart in the reference. */
+long jirf_train_scratch_generation(void);
+
 /* Per-kernel device time of the training operators called from this thread (HIP events around every launch;
  * serialises nothing but adds two events per launch).  jirf_train_kernel_times waits for the recorded launches,
  * returns the totals per label since the last call (names_out receives pointers to static strings) and starts
@@ -292,12 +301,16 @@ int jirf_train_smooth_l1(const float* pred, const float* target, float* grad, lo
 /* Sum of squares of a flat buffer in double (the norm of Optimizer.clip_grad_norm,
  * image_restoration_model.py:269-270), to device and / or host memory (host: synchronises `stream`). */
 int jirf_train_sumsq(const float* x, long n, double* out_dev, double* out_host, void* stream);
-/* Gradient clip (max_norm > 0: g *= min(max_norm / (sqrt(*sumsq_dev) + 1e-6), 1)) fused with one Adam step
- * on flat buffers p, g, m, v of n floats; step counts from 1.  torch_form 0: Jittor's update
+/* Gradient scale + clip + one Adam step on flat buffers p, g, m, v of n floats.  The gradient used is
+ * grad_scale * g (grad_scale = 1 / ranks after a SUM all-reduce of g: the data-parallel mean Jittor's optimizer
+ * takes under MPI, without a pass of its own over the buffer; 1 otherwise), clipped when max_norm > 0 by
+ * min(max_norm / (grad_scale * sqrt(*sumsq_dev) + 1e-6), 1) with *sumsq_dev the sum of squares of g as stored.
+ * step counts the optimiser's own updates from 1 (Adam's bias correction).  torch_form 0: Jittor's update
  * p -= m * lr * sqrt(1 - b1^t) / (1 - b0^t) / (sqrt(v) + eps) (what optimizer_g.step() runs,
  * image_restoration_model.py:215,271); 1: torch.optim.Adam's placement of eps. */
 int jirf_train_adam_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq_dev, float max_norm,
-                         float lr, float beta0, float beta1, float eps, int step, int torch_form, void* stream);
+                         float grad_scale, float lr, float beta0, float beta1, float eps, int step, int torch_form,
+                         void* stream);
 
 /* Convolution / Linear on device weights, as an implicit GEMM (the forward kernels of the inference path;
  * the weights are packed by a kernel inside the call).  w_kind selects how `w` is read:

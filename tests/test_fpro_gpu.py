@@ -95,6 +95,29 @@ def test_sots_sized_image_through_the_tiled_script_path():
     assert max_abs(got, want) < 1e-5
 
 
+def test_default_fpro_sots_sized_image_against_twenty_oracle_tile_calls():
+    """BASELINE configs[4], FPro half, end to end: the reference-default FPro (dim 48, blocks [2,3,6], ffn 3) on a
+    620 x 460 image through `restore_image` (pad to 624 x 464, 20 tiles of 256 x 256 overlapping by 158, mean blend,
+    unpad, clamp) against the ORACLE network called once per tile - what Dehaze/test_SOTS.py:132-180 does with the
+    reference network - with the oracle's own NumPy plumbing around it."""
+    from jirf_hip import harness as hh
+    from oracle import harness_oracle as ho
+    cfg = fo.default_config()
+    sd = make_fpro_state(cfg, seed=14, gain=0.6)
+    net = _build(cfg, sd)
+    x = synthetic_images(1, 460, 620, seed=55, sigma=10)
+    got = hh.restore_image(net, torch.from_numpy(x).cuda(), crop_size=256, overlap_size=158).cpu().numpy()
+    xp = ho.pad_to_factor(x)
+    split, starts = ho.splitimage(xp, 256, 158)
+    assert xp.shape[2:] == (464, 624) and len(split) == 20
+    outs = [fo.fpro_forward(sd, torch.from_numpy(np.ascontiguousarray(t)), cfg).numpy() for t in split]
+    want = ho.crop_clamp(ho.mergeimage(outs, starts, 256, xp.shape), 460, 620)
+    err = max_abs(got, want)
+    print(f"[FPro default, 620x460 as 20 tiles] max|dy| = {err:.2e} vs 20 oracle tile calls")
+    assert err < TOL
+    assert abs(psnr(got, x) - psnr(want, x)) < 0.01
+
+
 @pytest.mark.parametrize("B,C,heads,H,W", [
     (1, 96, 2, 64, 64),      # the prompt modules after decoder_level2 / 1 / refinement: 48 channels per head (matrix-core kernel)
     (2, 192, 2, 16, 24),     # after decoder_level3: 96 channels per head (the vector kernel)

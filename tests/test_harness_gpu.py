@@ -88,3 +88,30 @@ def test_ast_enclosing_square_policy():
     assert np.abs(got - want).max() < 1e-3
     with pytest.raises(ValueError, match="reflect padding"):
         hh.pad_to_square(torch.zeros(1, 3, 40, 200, device="cuda"))
+
+
+def test_restore_images_over_a_folder_of_mixed_sizes():
+    """harness.restore_images (the scripts' loop over a folder, shardable over ranks): with one rank every image
+    comes back in list order and equals its own restore_image call - batches of equal-sized neighbours run with
+    per-image semantics - for a stateless network and for HINT (every call cold)."""
+    from basicsr.models.archs import define_network
+    from jirf_hip import harness as hh
+    from oracle.weights import make_astv2_state, make_hint_state, synthetic_images
+    from tests.make_golden import ASTV2_SMALL, HINT_SMALL
+    sizes = [(83, 117), (83, 117), (83, 117), (64, 96), (83, 117), (64, 96), (64, 96)]
+    imgs = [torch.from_numpy(synthetic_images(1, h, w, seed=60 + i, sigma=25)[0]) for i, (h, w) in enumerate(sizes)]
+    for arch, cfg, make in (("ASTv2", ASTV2_SMALL, make_astv2_state), ("HINT", HINT_SMALL, make_hint_state)):
+        net = define_network(dict(cfg, type=arch))
+        net.load_state_dict(make(cfg, seed=2, gain=0.6))
+        net.cuda().eval()
+        got = hh.restore_images(net, imgs, batch=2)
+        kept = hh.restore_images(net, imgs, batch=3, balance=True, gather=False)
+        assert sorted(kept) == list(range(len(imgs)))
+        net.batch_mode = "per_image"
+        for i, x in enumerate(imgs):
+            if arch == "HINT":
+                net.qv_cache = None
+            want = hh.restore_image(net, x[None].cuda())[0]
+            assert tuple(got[i].shape) == (3,) + sizes[i]
+            assert float((got[i] - want).abs().max()) < 1e-5, (arch, i)
+            assert float((kept[i] - want).abs().max()) < 1e-5, (arch, i)

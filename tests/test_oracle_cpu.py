@@ -290,3 +290,106 @@ def test_named_jittor_assumptions_are_live_switches(field, value, arch):
     again = run(sd, torch.from_numpy(x), cfg).numpy()
     assert np.array_equal(base, again)
     assert np.abs(flipped - base).max() > 1e-6, f"{field}={value!r} did not reach the {arch} oracle"
+
+
+def _erf_gelu64(x):
+    return 0.5 * x * (1.0 + np.vectorize(math.erf)(x / math.sqrt(2.0)))
+
+
+def test_astv2_attention_mix_against_a_float64_loop_transcription():
+    """Attention.execute astv2_arch.py:174-200 written a second time, independently of oracle/astv2_oracle.py: NumPy
+    float64, explicit loops over (batch, head, row, column), the `att_ca` 1x1 convolution as a sum over the ROW index of
+    the squared-ReLU map and its output read back transposed - the index formula
+        Z[o, j] = sum_i W[o, i] R[i, j];  scale[r, c] = Z[c, r];  shift[r, c] = Z[ch + c, r]
+    that the three permutes of :187-196 amount to - and, beside it, the permutes applied literally with np.transpose.
+    Both must equal the torch oracle's attention matrix and output."""
+    from oracle import astv2_oracle as ao
+    rng = np.random.default_rng(7)
+    b, heads, ch, L = 2, 3, 5, 37
+    c = heads * ch
+    q, k, v = (rng.standard_normal((b, c, L)) for _ in range(3))
+    temp = rng.uniform(0.5, 2.0, (heads, 1, 1))
+    W = rng.standard_normal((2 * ch, ch)) * 0.4
+    bias = rng.standard_normal(2 * ch) * 0.1
+    t32 = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    attn_o, out_o = ao.attention_core(t32(q), t32(k), t32(v), t32(temp), t32(W.reshape(2 * ch, ch, 1, 1)), t32(bias), heads)
+    q4, k4, v4 = (a.astype(np.float32).astype(np.float64).reshape(b, heads, ch, L) for a in (q, k, v))
+    W, bias, temp = (a.astype(np.float32).astype(np.float64) for a in (W, bias, temp))
+    qn = q4 / np.sqrt((q4 ** 2).sum(-1, keepdims=True))
+    kn = k4 / np.sqrt((k4 ** 2).sum(-1, keepdims=True))
+    A = np.zeros((b, heads, ch, ch))
+    for n in range(b):
+        for h in range(heads):
+            for r in range(ch):
+                for col in range(ch):
+                    A[n, h, r, col] = float(np.dot(qn[n, h, r], kn[n, h, col])) * temp[h, 0, 0]
+    S = np.exp(A - A.max(-1, keepdims=True))
+    S /= S.sum(-1, keepdims=True)
+    R = np.maximum(A, 0.0) ** 2
+    R = _erf_gelu64(R) * R
+    # (1) the index formula, loops only
+    mixed = np.zeros_like(A)
+    for n in range(b):
+        for h in range(heads):
+            Z = np.zeros((2 * ch, ch))
+            for o in range(2 * ch):
+                for j in range(ch):
+                    Z[o, j] = sum(W[o, i] * R[n, h, i, j] for i in range(ch)) + bias[o]
+            for r in range(ch):
+                for col in range(ch):
+                    mixed[n, h, r, col] = S[n, h, r, col] * (1.0 + Z[col, r]) + Z[ch + col, r]
+    # (2) the reference's own sequence of permutes, literally
+    a1 = np.transpose(R, (0, 2, 1, 3))                                   # (b, ch_row, head, ch_col): NCHW of the conv
+    x_att = np.einsum("oi,nihj->nohj", W, a1) + bias.reshape(1, -1, 1, 1)  # (b, 2ch, head, ch_col)
+    x_att = np.transpose(x_att, (0, 2, 3, 1))                            # (b, head, ch_col, 2ch)
+    literal = S * (1.0 + x_att[..., :ch]) + x_att[..., ch:]
+    assert np.abs(mixed - literal).max() < 1e-12
+    out = (mixed @ v4).reshape(b, c, L)
+    assert np.abs(attn_o.numpy() - mixed).max() < 2e-5
+    assert np.abs(out_o.numpy() - out).max() < 2e-4 * max(1.0, np.abs(out).max())
+    # the transposition is visible: reading Z without it gives another matrix
+    wrong = S * (1.0 + np.transpose(x_att[..., :ch], (0, 1, 3, 2))) + np.transpose(x_att[..., ch:], (0, 1, 3, 2))
+    assert np.abs(wrong - mixed).max() > 1e-2
+
+
+def test_fpro_dynamic_filter_against_a_float64_loop_transcription():
+    """dynamic_filter_channel.execute fpro_arch.py:355-375 a second time, NumPy float64 with explicit loops over every
+    output element: global average pool -> 1x1 -> sigmoid gate -> eval-mode BatchNorm -> softmax over the 9 taps of each
+    of the 8 groups -> reflection-padded 3x3 unfold, channel c taking the taps of group c // (C / 8) - the grouping the
+    reshape (n, group, c // group, 9, h w) of :363-365 expresses.  Every element of low and high must match the oracle."""
+    from oracle import fpro_oracle as fo
+    from oracle.weights import make_fpro_state
+    from tests.make_golden import FPRO_SMALL
+    sd = make_fpro_state(FPRO_SMALL, seed=5)
+    pre = "splitFre.dyna_channel"
+    rng = np.random.default_rng(11)
+    n, c, h, w = 2, int(FPRO_SMALL["dim"]), 7, 9
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    p = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    low_o, high_o = fo.dynamic_filter(p, pre, torch.from_numpy(x))
+    f64 = lambda key: np.asarray(sd[pre + key], np.float64)
+    Wc, Wg = f64(".conv.weight")[:, :, 0, 0], f64(".conv_gate.weight")[:, :, 0, 0]
+    mean, var, gam, bet = f64(".bn.running_mean"), f64(".bn.running_var"), f64(".bn.weight"), f64(".bn.bias")
+    G, per = 8, c // 8
+    xd = x.astype(np.float64)
+    low = np.zeros_like(xd)
+    refl = lambda i, m: -i if i < 0 else (2 * (m - 1) - i if i >= m else i)
+    for b in range(n):
+        pooled = np.array([xd[b, ch].sum() / (h * w) for ch in range(c)])
+        f = Wc @ pooled
+        f = f * (1.0 / (1.0 + np.exp(-(Wg @ f))))
+        f = (f - mean) / np.sqrt(var + 1e-5) * gam + bet
+        taps = f.reshape(G, 9)
+        taps = np.exp(taps - taps.max(1, keepdims=True))
+        taps /= taps.sum(1, keepdims=True)
+        for ch in range(c):
+            g = ch // per
+            for y in range(h):
+                for xx in range(w):
+                    acc = 0.0
+                    for ky in range(3):
+                        for kx in range(3):
+                            acc += taps[g, ky * 3 + kx] * xd[b, ch, refl(y + ky - 1, h), refl(xx + kx - 1, w)]
+                    low[b, ch, y, xx] = acc
+    assert np.abs(low_o.numpy() - low).max() < 2e-6
+    assert np.abs(high_o.numpy() - (xd - low)).max() < 2e-6

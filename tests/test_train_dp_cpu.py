@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from jirf_hip.train import average_flat_gradients, broadcast_flat_parameters, reduce_loss
+from jirf_hip.train import allreduce_flat_gradients, average_flat_gradients, broadcast_flat_parameters, reduce_loss
 
 
 def _free_port():
@@ -43,6 +43,11 @@ def _worker(rank, world, port, out):
             g = torch.from_numpy(g_local.copy())
             average_flat_gradients(g)
             p = torch.from_numpy(_adam(p.numpy(), g.numpy(), m, v, step).astype(np.float32))
+        # what the training step does: the SUM stays in the buffer and 1 / ranks goes to the update as grad_scale
+        gs = torch.from_numpy(g_local.copy())
+        scale = allreduce_flat_gradients(gs)
+        assert scale == 1.0 / world
+        assert np.allclose(gs.numpy() * np.float32(scale), g.numpy(), rtol=0, atol=1e-9)
         loss = reduce_loss(1.0 + rank, "cpu")
         out.put((rank, p0, g.numpy().copy(), p.numpy().copy(), loss))
     finally:
@@ -70,8 +75,31 @@ def test_two_rank_gradient_average_keeps_replicas_identical():
     assert l_a == l_b == 1.5
 
 
+def _solo_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = torch.arange(8, dtype=torch.float32)
+        scale = allreduce_flat_gradients(g)                          # the collective runs over the one rank
+        out.put((scale, g.numpy().copy(), reduce_loss(0.25, "cpu")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_group_still_takes_the_collective_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo_worker, args=(_free_port(), q))
+    p.start()
+    scale, g, loss = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert scale == 1.0 and np.array_equal(g, np.arange(8, dtype=np.float32)) and loss == 0.25
+
+
 def test_single_process_is_a_no_op():
     g = torch.arange(8, dtype=torch.float32)
     average_flat_gradients(g)
     assert torch.equal(g, torch.arange(8, dtype=torch.float32))
+    assert allreduce_flat_gradients(g) == 1.0
     assert reduce_loss(0.25, "cpu") == 0.25

@@ -44,10 +44,13 @@ def test_smooth_l1_loss_and_gradient():
     assert (np.abs(pred - tgt) > 1).any() and (np.abs(pred - tgt) < 1).any()      # both branches
 
 
-@pytest.mark.parametrize("torch_form", [0, 1])
-def test_clip_and_adam_step(torch_form):
+@pytest.mark.parametrize("torch_form,ranks", [(0, 1), (1, 1), (0, 4)])
+def test_clip_and_adam_step(torch_form, ranks):
+    """ranks > 1: the buffer holds the SUM over the ranks (what the all-reduce leaves) and grad_scale = 1 / ranks
+    makes the update that of the mean, the clip's norm included."""
     n = 100003
     p, g = rnd(n, seed=3), rnd(n, scale=1e-3, seed=4)
+    g_sum = (g * np.float32(ranks)).astype(np.float32)        # a power of two: g_sum / ranks == g exactly
     m, v = rnd(n, scale=1e-4, seed=5), np.abs(rnd(n, scale=1e-6, seed=6))
     lr, b0, b1, eps, step, max_norm = 2e-4, 0.9, 0.999, 1e-8, 7, 0.01
     # Jittor: Optimizer.clip_grad_norm(max_norm, 2) then Adam.step
@@ -59,13 +62,13 @@ def test_clip_and_adam_step(torch_form):
         p2 = p - lr / (1 - b0 ** step) * m2 / (np.sqrt(v2) / np.sqrt(1 - b1 ** step) + eps)
     else:
         p2 = p - m2 * (lr * np.sqrt(1 - b1 ** step) / (1 - b0 ** step)) / (np.sqrt(v2) + eps)
-    pd, gd, md, vd = dev(p), dev(g), dev(m), dev(v)
+    pd, gd, md, vd = dev(p), dev(g_sum), dev(m), dev(v)
     ss = torch.zeros(1, dtype=torch.float64, device="cuda")
     hs = C.c_double()
     call("jirf_train_sumsq", ptr(gd), n, ptr(ss), C.byref(hs), stream())
-    assert abs(hs.value - total ** 2) < 1e-9 * total ** 2
-    call("jirf_train_adam_step", ptr(pd), ptr(gd), ptr(md), ptr(vd), n, ptr(ss), max_norm, lr, b0, b1, eps, step,
-         torch_form, stream())
+    assert abs(hs.value - (ranks * total) ** 2) < 1e-9 * (ranks * total) ** 2
+    call("jirf_train_adam_step", ptr(pd), ptr(gd), ptr(md), ptr(vd), n, ptr(ss), max_norm, 1.0 / ranks, lr, b0, b1, eps,
+         step, torch_form, stream())
     assert total > max_norm                                      # the clip is active
     assert rel_err(md.cpu().numpy(), m2) < 1e-5 and rel_err(vd.cpu().numpy(), v2) < 1e-5
     got = pd.cpu().numpy()

@@ -239,6 +239,84 @@ def test_captured_step_equals_the_step_queued_kernel_by_kernel():
     assert torch.equal(eager.p, graph.p) and torch.equal(eager.m, graph.m) and torch.equal(eager.v, graph.v)
 
 
+_GROWING_SHAPES_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/image-restoration_amd"]
+from tests.test_train_step_gpu import _cfg, _state, _data
+from jirf_hip import lib
+from jirf_hip.train import AstTrainStep
+cfg = _cfg(); sd = _state(cfg, 6)
+shapes = [(1, 128)] * 3 + [(2, 128)] * 3 + [(2, 256)] * 2 + [(2, 128)] * 2
+def run(tr, other=None):
+    out = []
+    for it, (B, S) in enumerate(shapes, start=1):
+        lq, gt = _data(B, S, 70 + it)
+        out.append((tr.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), it), tr.output.clone()))
+        if other is not None and it == 6:
+            # a second trainer of the process grows the shared scratch while `tr` holds a captured step
+            g0 = lib().jirf_train_scratch_generation()
+            lq2, gt2 = _data(2, 256, 5)
+            other.forward_backward(torch.from_numpy(lq2), torch.from_numpy(gt2))
+            assert lib().jirf_train_scratch_generation() > g0, "the larger shape was expected to grow the scratch"
+    return out
+# the captured trainer runs FIRST and alone: nothing has sized the process-wide scratch for it
+graph = AstTrainStep(cfg, sd, seed=3, use_graph=True)
+a = run(graph, AstTrainStep(cfg, sd, seed=9))
+assert graph._graph is not None
+# a capture at a shape no eager step has sized is refused cleanly and the step falls back to kernel-by-kernel
+fresh = AstTrainStep(cfg, sd, seed=3, use_graph=True)
+lq, gt = _data(1, 128, 71)
+fresh.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), 1)
+fresh._eager_shapes.add((2, 3, 384, 384))
+lq, gt = _data(2, 384, 72)
+l2 = fresh.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), 2)
+assert np.isfinite(l2) and fresh._graph is None
+l3 = fresh.optimize_parameters(torch.from_numpy(lq), torch.from_numpy(gt), 3)
+assert np.isfinite(l3) and fresh._graph is not None
+eager = AstTrainStep(cfg, sd, seed=3)
+b = run(eager)
+for i, ((la, oa), (lb, ob)) in enumerate(zip(a, b)):
+    assert la == lb and torch.equal(oa, ob), (i, la, lb)
+assert torch.equal(graph.p, eager.p)
+print("GROWING-SHAPES-OK")
+"""
+
+
+def test_captured_step_when_the_shape_grows_in_a_fresh_process():
+    """The captured trainer alone in a new process, stepping at a small shape first and larger ones later, with a
+    second trainer growing the library's shared scratch under its live capture: every step must equal the eager
+    trainer's bit for bit (a capture at a new shape follows one eager step there; a moved scratch buffer drops the
+    recorded step; a capture that would have to grow the scratch is refused and the step runs eagerly)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _GROWING_SHAPES_SCRIPT, root], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "GROWING-SHAPES-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_resume_keeps_the_optimisers_own_step_count():
+    """Adam's bias correction counts the optimiser's updates (jt.optim.Adam's n_step), not the caller's iteration: a
+    trainer started at current_iter = 5000 with fresh moments makes the first-update step, and a trainer resumed from
+    optimizer_state_dict() continues bit-identically."""
+    from jirf_hip.train import AstTrainStep
+    cfg = _cfg()
+    sd = _state(cfg, 6)
+    lq, gt = _data(1, 128, 90)
+    lq, gt = torch.from_numpy(lq), torch.from_numpy(gt)
+    a = AstTrainStep(cfg, sd, drop_path_rate=0.0, use_grad_clip=False)
+    b = AstTrainStep(cfg, sd, drop_path_rate=0.0, use_grad_clip=False)
+    a.optimize_parameters(lq, gt, 1)
+    b.optimize_parameters(lq, gt, 5000)
+    assert a.opt_step == b.opt_step == 1 and torch.equal(a.p, b.p)
+    a.optimize_parameters(lq, gt, 2)
+    c = AstTrainStep(cfg, a.state_dict(), drop_path_rate=0.0, use_grad_clip=False)
+    c.load_optimizer_state_dict(a.optimizer_state_dict())
+    a.optimize_parameters(lq, gt, 3)
+    c.optimize_parameters(lq, gt, 3)
+    assert c.opt_step == 3 and torch.equal(a.p, c.p) and torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
+
+
 def test_gradient_mean_over_two_shards_equals_the_batch_gradient():
     """What the data-parallel step relies on: with per-image semantics the gradient of the mean loss over a batch is
     the mean of the gradients of its shards (here the two halves a 2-rank job would hold), so averaging the flat

@@ -79,7 +79,8 @@ def test_ssim_matches_oracle(shape, border, y):
         a, b = a[..., 0], b[..., 0]
     want = mo.calculate_ssim(a, b, border, test_y_channel=y)
     got = calculate_ssim(a, b, border, test_y_channel=y)
-    assert abs(got - want) < 1e-5, (got, want)
+    # the luma form is float64 end to end in the reference (_ssim_cly :222-223) and here
+    assert abs(got - want) < (1e-10 if y else 1e-5), (got, want)
     assert abs(calculate_ssim(a, a, border, test_y_channel=y) - 1.0) < 1e-6
     if not y and a.ndim == 3:
         fa, fb = a.astype(np.float32) / 255.0, b.astype(np.float32) / 255.0          # [0, 1] images: C1, C2 from max 1
@@ -90,6 +91,21 @@ def test_ssim_matches_oracle(shape, border, y):
         assert abs(calculate_ssim(ta[None], tb[None], border) - want01) < 1e-5
         chw = calculate_ssim(a.transpose(2, 0, 1), b.transpose(2, 0, 1), border, input_order="CHW")
         assert abs(chw - want) < 1e-5
+
+
+def test_ssim_luma_form_on_flat_regions_is_float64_exact():
+    """Flat and nearly flat regions are where sigma = E[x^2] - mu^2 cancels: bright plateaus with +-1 grey level of
+    noise.  In float32 the variances carry errors of about 4e-3 against C2 = 58.5; the float64 path agrees with the
+    oracle's float64 evaluation to 1e-10."""
+    from basicsr.metrics import calculate_ssim
+    rng = np.random.default_rng(5)
+    a = np.full((72, 88, 3), 250, np.uint8)
+    a[:, 44:] = 17
+    a[20:40] = rng.integers(0, 256, (20, 88, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-1, 2, a.shape), 0, 255).astype(np.uint8)
+    want = mo.calculate_ssim(a, b, 0, test_y_channel=True)
+    got = calculate_ssim(a, b, 0, test_y_channel=True)
+    assert abs(got - want) < 1e-10, (got, want)
 
 
 def test_validation_loop_matches_oracle(tmp_path):

@@ -53,3 +53,61 @@ def test_static_entry_point_rejects_sizes_beyond_its_array():
     rc = L.jirf_op_ln_conv1x1_static(ptr(x), ptr(x), ptr(x), 1, ptr(x), ptr(x), 5, 48, 48, 256 * 1024, stream())
     assert rc == -1 and "pixels" in jirf_hip.last_error()
     torch.cuda.synchronize()
+
+
+def _operands(kind, B, C, Cout, P, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((B, C, P)) * 2 + 0.5).astype(np.float32)
+    lw = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    lb = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    w = (rng.standard_normal((Cout, C)) * C ** -0.5).astype(np.float32)
+    return w, dev(x), dev(lw), dev(lb), dev(w)
+
+
+@pytest.mark.parametrize("shape", [(2, 384, 1020, 4096), (2, 96, 510, 4096)])
+def test_static_entry_point_leaves_the_devices_free_memory_unchanged(shape):
+    """What the name promises, measured: hipMemGetInfo before and after a call reports the same free memory (the
+    packed weights and the statistics go to the library's static device array), while the entry point it is a
+    variant of allocates and frees inside the call.  One warm-up call first: the first call on a device looks the
+    array's address up and may load the code object."""
+    L = jirf_hip.lib()
+    B, C, Cout, P = shape
+    w, xd, lwd, lbd, wd = _operands(1, B, C, Cout, P, 3)
+    got = torch.empty((B, Cout, P), device="cuda")
+    args = (ptr(xd), ptr(lwd), ptr(lbd), 1, ptr(wd), ptr(got), B, C, Cout, P, stream())
+    call("jirf_op_ln_conv1x1_static", *args)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    lows = []
+    for _ in range(3):
+        jirf_hip.check(L.jirf_op_ln_conv1x1_static(*args))
+        lows.append(torch.cuda.mem_get_info()[0])          # queried while the call's kernels may still run
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before and all(v == free_before for v in lows), (free_before, lows, free_after)
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("first,second", [((2, 384, 1020, 4096), (1, 320, 254, 130)),
+                                          ((2, 96, 510, 4096), (1, 48, 144, 1000))])
+def test_static_entry_point_inside_a_stream_capture(kind, first, second):
+    """The callers it exists for: the second call of each pair is recorded into a hipGraph (no allocation, no
+    synchronisation inside the call, so the capture stays valid) and replayed twice on new input data; the output
+    equals the allocating entry point's bit for bit.  The first call of the pair runs outside the capture, which is
+    the documented requirement: one call per device before any capture."""
+    got, want = _both(kind, *first, seed=21)
+    assert np.array_equal(got, want)
+    B, C, Cout, P = second
+    w, xd, lwd, lbd, wd = _operands(kind, B, C, Cout, P, 22)
+    want = torch.full((B, Cout, P), float("nan"), device="cuda")
+    got = torch.full((B, Cout, P), float("nan"), device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        jirf_hip.check(jirf_hip.lib().jirf_op_ln_conv1x1_static(ptr(xd), ptr(lwd), ptr(lbd), kind, ptr(wd), ptr(got), B, C,
+                                                                Cout, P, stream()))
+    for rep in range(2):
+        xd.copy_(xd * 0.5 + 0.25 * rep)                    # the recorded call reads its operands at replay time
+        graph.replay()
+        torch.cuda.synchronize()
+        call("jirf_op_ln_conv1x1", ptr(xd), ptr(lwd), ptr(lbd), kind, hptr(w), ptr(want), B, C, Cout, P, stream())
+        assert np.array_equal(got.cpu().numpy(), want.cpu().numpy()), f"replay {rep}"
