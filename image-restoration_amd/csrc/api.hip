@@ -412,6 +412,14 @@ int jirf_op_conv3x3(const float* x, const float* w_host, const float* bias_host,
   });
 }
 
+int jirf_op_gelu_error_scan(float hi, double* out4_host, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(out4_host, JIRF_EINVAL, "gelu_error_scan: null output");
+    gelu_error_scan(hi, out4_host, static_cast<hipStream_t>(stream));
+    return JIRF_OK;
+  });
+}
+
 int jirf_op_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int B, int C,
                       int H, int W, int gate, void* stream) {
   return guarded([&] {

@@ -181,6 +181,9 @@ bool try_launch_conv3x3_fewout(const struct GemmArgs& a, hipStream_t s);
 void launch_dwconv3x3(TV x, const float* w, const float* bias, TV y, int B, int C, int H, int W,
                       int gate, hipStream_t s, int wmod = 0, int wconv = 0);
 
+// Accuracy of the branch-free GELU over every float in [-hi, hi] (see gelu_scan_kernel); synchronises `s`.
+void gelu_error_scan(float hi, double out[4], hipStream_t s);
+
 // ---- HINT channel attention ------------------------------------------------------------------
 struct HintAttnShape {
   int B, C, P;
@@ -271,6 +274,38 @@ void set_current_clock(KernelClock* c);
 // Returns a pointer that stays valid for the life of the process (labels carry shapes).
 const char* intern_label(const char* fmt, ...);
 #ifdef __HIPCC__
+// ---- GELU (exact erf form, 0.5 v (1 + erf(v / sqrt 2)): nn.GELU of the reference's framework) -------------------
+// Branch-free, eleven vector instructions, one of them transcendental (the C library's erff costs two code paths
+// whenever the lanes of a wave straddle |x| = 1, which activations do).  With u = |v|,
+//     half_erfc(u) = 0.5 erfc(u / sqrt 2) = 2^-(1 + u Q(u)),     gelu(v) = max(v, 0) - u half_erfc(u).
+// -log2 erfc(u / sqrt 2) is smooth and nearly linear-to-quadratic on the whole axis (erfc has no real zero), so ONE
+// polynomial u Q(u) of degree 8 serves every u: the coefficients are the minimax fit on [0, 6] of the error weighted
+// by erfc itself (what reaches the result), 1.6e-8 before rounding.  Past 6 the polynomial keeps rising (leading
+// coefficient > 0), the power of two underflows to 0 and gelu(v) = max(v, 0) exactly, as erfc < 2^-30 there asks.
+// Measured over every float in [-8.5, 8.5] (jirf_op_gelu_error_scan): |2 half_erfc - erfc| <= 2e-7 and gelu within
+// 2 ulp of the float64 value.  NaN stays NaN; +inf gives NaN (inf * 0) where the erf form gives inf.
+__device__ __forceinline__ float half_erfc_abs(float u) {
+  float r = fmaf(u, 2.834913e-06f, -3.937769e-05f);
+  r = fmaf(r, u, 0.00018618023f);
+  r = fmaf(r, u, 0.0001369364f);
+  r = fmaf(r, u, -0.00706342f);
+  r = fmaf(r, u, 0.05249618f);
+  r = fmaf(r, u, 0.4592082f);
+  r = fmaf(r, u, 1.1511052f);
+  return __builtin_amdgcn_exp2f(-fmaf(r, u, 1.0f));      // v_exp_f32
+}
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float u = fabsf(v);
+  return fmaf(-u, half_erfc_abs(u), fmaxf(v, 0.0f));
+}
+// d gelu / d v = Phi(v) + v phi(v), Phi(v) = v >= 0 ? 1 - half_erfc(|v|) : half_erfc(|v|)
+__device__ __forceinline__ float gelu_grad_fast(float v) {
+  const float h = half_erfc_abs(fabsf(v));
+  const float cdf = v >= 0.0f ? 1.0f - h : h;
+  // exp(-v^2 / 2) / sqrt(2 pi) = 2^(-v^2 log2(e) / 2) * 0.3989...
+  return fmaf(v * 0.39894228040143267794f, __builtin_amdgcn_exp2f(v * v * -0.72134752044448170368f), cdf);
+}
+
 // Blocks b and b + 8 share an XCD (round-robin dispatch).  Remap so that consecutive logical
 // tiles — which share the same activation columns — land on one XCD's L2.  Bijective for any n.
 __device__ __forceinline__ int xcd_remap(int id, int n) {

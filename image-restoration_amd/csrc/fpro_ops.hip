@@ -11,9 +11,7 @@
 
 namespace jirf {
 
-__device__ __forceinline__ float gelu_erf_f(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-}
+__device__ __forceinline__ float gelu_erf_f(float v) { return gelu_fast(v); }
 
 // ---- per-channel spatial mean: out[b][c] = mean_p x[b][c][p] -------------------------------------
 __global__ __launch_bounds__(256) void channel_mean_kernel(const float* __restrict__ x, long x_bs,

@@ -23,9 +23,7 @@ namespace jirf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float gelu_erf(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-}
+__device__ __forceinline__ float gelu_erf(float v) { return gelu_fast(v); }
 
 // Epilogue of one 32 x 32 accumulator tile: rows row0 + (r & 3) + 8 * (r >> 2) (row0 already holds
 // the lane half's + 4), column `col` (< P).  Everything the epilogue reads is gathered first so

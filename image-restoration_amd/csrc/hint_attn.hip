@@ -33,9 +33,7 @@ constexpr int ST_CH = 32;   // pixels per staged chunk
 constexpr int ST_LD = 33;   // LDS row stride (floats)
 constexpr float NORM_EPS = 1e-30f;
 
-__device__ __forceinline__ float gelu_erf_a(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-}
+__device__ __forceinline__ float gelu_erf_a(float v) { return gelu_fast(v); }
 
 // ------------------------------------------------------------------------------------------------
 // 1. statistics

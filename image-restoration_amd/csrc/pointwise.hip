@@ -4,14 +4,13 @@
 // Activations are planar [channel][pixel]; a wave's 64 lanes always sit on 64 (or 256) adjacent
 // pixels, so every global access is a full 256-B / 1-KiB row segment.
 #include <algorithm>
+#include <cstring>
 
 #include "common.h"
 
 namespace jirf {
 
-__device__ __forceinline__ float gelu_erf_pw(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-}
+__device__ __forceinline__ float gelu_erf_pw(float v) { return gelu_fast(v); }
 
 // ---- per-pixel LayerNorm over channels ---------------------------------------------------------
 // One lane per pixel.  Pass 1 sums the channels, pass 2 sums squared deviations (the two-pass
@@ -845,6 +844,65 @@ bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
 #undef JIRF_FEWOUT
   JIRF_HIP_CHECK(hipGetLastError());
   return true;
+}
+
+// ---- accuracy scan of the branch-free GELU (diagnostics) ------------------------------------------------------
+// Every float u in [0, hi] by bit pattern, both signs: the float64 value of erfc(u / sqrt 2) against 2 half_erfc_abs(u),
+// and gelu_fast(+-u) against 0.5 v (1 + erf(v / sqrt 2)) in float64 and against the same form on the C library's erff
+// (the previous implementation).  out [grid][4] maxima per workgroup: |erfc error|, |gelu error|, gelu error in units
+// of the float spacing at the exact value, |gelu_fast - erff form|.
+__global__ __launch_bounds__(256) void gelu_scan_kernel(unsigned last_bits, double* __restrict__ part) {
+  __shared__ double red[4][256];
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i <= last_bits;
+       i += (unsigned long long)gridDim.x * 256) {
+    const float u = __uint_as_float((unsigned)i);
+    const double ud = (double)u;
+    const double ec = erfc(ud * 0.70710678118654752440);
+    m0 = fmax(m0, fabs(2.0 * (double)half_erfc_abs(u) - ec));
+#pragma unroll
+    for (int sgn = 0; sgn < 2; ++sgn) {
+      const float v = sgn ? -u : u;
+      const double want = sgn ? -0.5 * ud * ec : 0.5 * ud * (2.0 - ec);
+      const float got = gelu_fast(v);
+      const double e = fabs((double)got - want);
+      m1 = fmax(m1, e);
+      const float wf = (float)want;
+      const float ulp = fabsf(__uint_as_float(__float_as_uint(fabsf(wf)) + 1u) - fabsf(wf));
+      if (fabsf(wf) > 1e-30f) m2 = fmax(m2, e / (double)ulp);
+      const float old = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      m3 = fmax(m3, fabs((double)got - (double)old));
+    }
+  }
+  red[0][threadIdx.x] = m0; red[1][threadIdx.x] = m1; red[2][threadIdx.x] = m2; red[3][threadIdx.x] = m3;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int j = 0; j < 4; ++j) red[j][threadIdx.x] = fmax(red[j][threadIdx.x], red[j][threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+void gelu_error_scan(float hi, double out[4], hipStream_t s) {
+  JIRF_REQUIRE(hi > 0.f && hi < 1e30f, JIRF_EINVAL, "gelu scan: bad upper bound %g", (double)hi);
+  unsigned bits;
+  std::memcpy(&bits, &hi, 4);
+  const int grid = 4096;
+  double* part = nullptr;
+  JIRF_HIP_CHECK(hipMalloc(&part, (size_t)grid * 4 * sizeof(double)));
+  hipLaunchKernelGGL(gelu_scan_kernel, dim3(grid), dim3(256), 0, s, bits, part);
+  std::vector<double> host((size_t)grid * 4);
+  const hipError_t e1 = hipGetLastError();
+  const hipError_t e2 = hipMemcpyAsync(host.data(), part, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+  const hipError_t e3 = hipStreamSynchronize(s);
+  (void)hipFree(part);
+  JIRF_HIP_CHECK(e1);
+  JIRF_HIP_CHECK(e2);
+  JIRF_HIP_CHECK(e3);
+  for (int j = 0; j < 4; ++j) out[j] = 0.0;
+  for (int b = 0; b < grid; ++b)
+    for (int j = 0; j < 4; ++j) out[j] = std::max(out[j], host[(size_t)b * 4 + j]);
 }
 
 }  // namespace jirf

@@ -21,11 +21,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float v) { return gelu_fast(v); }
 // d/dv [0.5 v (1 + erf(v / sqrt 2))] = 0.5 (1 + erf(v / sqrt 2)) + v exp(-v^2 / 2) / sqrt(2 pi)
-__device__ __forceinline__ float gelu_grad_f(float v) {
-  return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * expf(-0.5f * v * v) * 0.39894228040143267794f;
-}
+__device__ __forceinline__ float gelu_grad_f(float v) { return gelu_grad_fast(v); }
 
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
   const int tid = threadIdx.x;

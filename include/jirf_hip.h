@@ -154,6 +154,13 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
 #define JIRF_STATIC_MAX_PIXELS (1024 * 1024)
 int jirf_op_ln_conv1x1_static(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
                               const float* w_dev, float* y, int B, int Cin, int Cout, int P, void* stream);
+/* Diagnostics, no counterpart in the reference.  The kernels evaluate nn.GELU's exact form
+ * 0.5 v (1 + erf(v / sqrt 2)) (hint_arch.py:184,209,226; ast_arch.py:384,456-466; astv2_arch.py:139,184;
+ * fpro_arch.py:39-44) through one branch-free polynomial + power of two for erfc instead of the C library's erff.
+ * This scans EVERY float in [-hi, hi] on the device and returns maxima to out4_host (host, 4 doubles):
+ * [0] |2^-(...) form - erfc(u / sqrt 2)| against float64, [1] |gelu - float64 gelu|, [2] the same in units of the
+ * float spacing at the exact value, [3] |gelu - the erff form|.  Synchronises `stream`. */
+int jirf_op_gelu_error_scan(float hi, double* out4_host, void* stream);
 /* Dense 3x3, stride 1, zero pad 1 (hint_arch.py:441-448,459-466,479-486,648-655).
  * w_host [Cout,Cin,3,3].  mode 0: plain; 1: followed by pixel-unshuffle(2)
  * (hint_arch.py:35-56); 2: followed by pixel-shuffle(2); res (NULL or [B,Cout,H,W]) is

@@ -1,4 +1,6 @@
 """Known-answer tests of the single-kernel entry points against the oracle's ops (GPU)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -139,3 +141,18 @@ def test_layernorm_large_plane(kind, C):
     y = torch.empty(B, C, P, device="cuda")
     call("jirf_op_layernorm", ptr(xd), ptr(lwd), ptr(lbd), ptr(y), B, C, P, kind, stream())
     assert max_abs(y.cpu(), n.reshape(B, C, P)) < 2e-5
+
+
+def test_gelu_over_every_float():
+    """The kernels evaluate nn.GELU's erf form through one branch-free polynomial + power of two for erfc.  Scanned on
+    the device over EVERY float in [-8.5, 8.5] (that is |x| <= 6 for erf(x) itself, x = v / sqrt 2) against float64:
+    the erfc value within 2e-7 absolute, gelu within 2.5 spacings of the exact value's float, and within 5e-7 of the
+    form on the C library's erff that it replaced.  A second scan up to 1e30 checks the tail (gelu(v) -> max(v, 0))."""
+    out = (C.c_double * 4)()
+    call("jirf_op_gelu_error_scan", 8.5, out, stream())
+    erfc_err, gelu_err, gelu_ulp, vs_erff = (float(v) for v in out)
+    print(f"[gelu scan, every float in [-8.5, 8.5]] max |erfc err| = {erfc_err:.3e}, max |gelu err| = {gelu_err:.3e} "
+          f"({gelu_ulp:.2f} spacings), max |gelu - erff form| = {vs_erff:.3e}")
+    assert erfc_err <= 2e-7 and gelu_ulp <= 2.5 and gelu_err <= 1e-6 and vs_erff <= 1e-6
+    call("jirf_op_gelu_error_scan", 1e30, out, stream())
+    assert float(out[0]) <= 2e-7 and float(out[2]) <= 2.5 and np.isfinite(float(out[1]))
