@@ -314,6 +314,54 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
   });
 }
 
+int jirf_op_gdfn(const float* x, float* y, int B, int C, int hidden, int H, int W, int ln_kind, const float* ln_w_host,
+                 const float* ln_b_host, const float* w_in_host, const float* b_in_host, const float* w_dw_host,
+                 const float* b_dw_host, const float* w_out_host, const float* b_out_host, int fused, void* stream) {
+  return guarded([&] {
+    JIRF_REQUIRE(x && y && x != y && B > 0 && C > 0 && hidden > 0 && H > 0 && W > 0 && ln_w_host && w_in_host && w_dw_host &&
+                     w_out_host, JIRF_EINVAL, "gdfn: bad arguments");
+    JIRF_REQUIRE(ln_kind == 1 || ln_kind == 2, JIRF_EINVAL, "gdfn: ln_kind %d", ln_kind);
+    JIRF_REQUIRE(ln_kind == 2 || ln_b_host, JIRF_EINVAL, "gdfn: WithBias needs ln_b");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int P = H * W, h = hidden;
+    WeightPool pool;
+    const TV xv = tv(const_cast<float*>(x), (long)C * P), yv = tv(y, (long)C * P);
+    if (fused) {
+      JIRF_REQUIRE(gdfn_fused_supported(C, h, H, W), JIRF_EINVAL,
+                   "gdfn: the one-kernel form is built for 96 channels, hidden <= 256 and planes at least 32 wide "
+                   "(got C=%d hidden=%d %dx%d)", C, h, H, W);
+      const GdfnFusedW w = pack_upload_gdfn_fused(pool, C, h, ln_w_host, ln_kind == 1 ? ln_b_host : nullptr, w_in_host,
+                                                  b_in_host, w_dw_host, b_dw_host, w_out_host, b_out_host);
+      launch_gdfn_fused(w, xv, yv, B, H, W, ln_kind == 1, s);
+    } else {
+      // the three launches the networks use for the shapes the one-kernel form does not take
+      const PackedW pin = pack_upload_ln_1x1(pool, w_in_host, b_in_host, ln_w_host, ln_kind == 1 ? ln_b_host : nullptr, 2 * h, C);
+      const PackedW pout = pack_upload_1x1(pool, w_out_host, b_out_host, C, h);
+      const float* dww = pool.upload(w_dw_host, (size_t)2 * h * 9);
+      const float* dwb = b_dw_host ? pool.upload(b_dw_host, (size_t)2 * h) : nullptr;
+      DeviceBuffer t1, t2, stats;
+      t1.ensure((size_t)B * 2 * h * P * 4);
+      t2.ensure((size_t)B * h * P * 4);
+      stats.ensure((size_t)2 * B * P * 4);
+      float* mu = static_cast<float*>(stats.p);
+      float* rstd = mu + (size_t)B * P;
+      if (!gemm_ln_inline(C)) launch_ln_stats(xv, mu, rstd, B, C, P, s);
+      GemmArgs g{};
+      g.B = B; g.M = 2 * h; g.K = C; g.P = P; g.Mpad = pin.Mpad; g.wt = pin.wt; g.bias = pin.bias;
+      g.x = xv; g.y = tv(static_cast<float*>(t1.p), (long)2 * h * P); g.imgs_per_group = 1; g.epi = EP_STORE;
+      g.mu = mu; g.rstd = rstd; g.ln_center = ln_kind == 1;
+      launch_gemm(g, LD_LN, s);
+      launch_dwconv3x3(g.y, dww, dwb, tv(static_cast<float*>(t2.p), (long)h * P), B, 2 * h, H, W, 1, s);
+      GemmArgs o{};
+      o.B = B; o.M = C; o.K = h; o.P = P; o.Mpad = pout.Mpad; o.wt = pout.wt; o.bias = pout.bias;
+      o.x = tv(static_cast<float*>(t2.p), (long)h * P); o.y = yv; o.imgs_per_group = 1; o.epi = EP_RESID; o.r = xv;
+      launch_gemm(o, LD_PLAIN, s);
+    }
+    JIRF_HIP_CHECK(hipStreamSynchronize(s));
+    return JIRF_OK;
+  });
+}
+
 // ---- the entry point that allocates nothing ---------------------------------------------------------
 // jirf_op_ln_conv1x1 keeps two things in device memory besides its input and output: the weights in
 // the GEMM's K-major packing and, for Cin > 256, the per-pixel LayerNorm statistics.  Here both live in

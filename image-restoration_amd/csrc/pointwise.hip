@@ -850,7 +850,8 @@ bool try_launch_conv3x3_fewout(const GemmArgs& a, hipStream_t s) {
 // Every float u in [0, hi] by bit pattern, both signs: the float64 value of erfc(u / sqrt 2) against 2 half_erfc_abs(u),
 // and gelu_fast(+-u) against 0.5 v (1 + erf(v / sqrt 2)) in float64 and against the same form on the C library's erff
 // (the previous implementation).  out [grid][4] maxima per workgroup: |erfc error|, |gelu error|, gelu error in units
-// of the float spacing at the exact value, |gelu_fast - erff form|.
+// of the float spacing at the exact value (v >= 0 only: for v < 0 gelu decays to zero like erfc and the absolute error
+// is the measure), |gelu_fast - erff form|.
 __global__ __launch_bounds__(256) void gelu_scan_kernel(unsigned last_bits, double* __restrict__ part) {
   __shared__ double red[4][256];
   double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256) void gelu_scan_kernel(unsigned last_bits, doub
       m1 = fmax(m1, e);
       const float wf = (float)want;
       const float ulp = fabsf(__uint_as_float(__float_as_uint(fabsf(wf)) + 1u) - fabsf(wf));
-      if (fabsf(wf) > 1e-30f) m2 = fmax(m2, e / (double)ulp);
+      if (!sgn && fabsf(wf) > 1e-30f) m2 = fmax(m2, e / (double)ulp);   // v < 0: gelu -> 0-, only the absolute error means anything
       const float old = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
       m3 = fmax(m3, fabs((double)got - (double)old));
     }
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(256) void gelu_scan_kernel(unsigned last_bits, doub
 }
 
 void gelu_error_scan(float hi, double out[4], hipStream_t s) {
-  JIRF_REQUIRE(hi > 0.f && hi < 1e30f, JIRF_EINVAL, "gelu scan: bad upper bound %g", (double)hi);
+  JIRF_REQUIRE(hi > 0.f && hi <= 3e38f, JIRF_EINVAL, "gelu scan: bad upper bound %g", (double)hi);
   unsigned bits;
   std::memcpy(&bits, &hi, 4);
   const int grid = 4096;

@@ -158,4 +158,20 @@ PackedW pack_upload_ln_1x1(WeightPool& pool, const float* w, const float* bias, 
 PackedW pack_upload_3x3(WeightPool& pool, const float* w, const float* bias, int M, int Cin);
 PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, int M, int Cin, int ks);
 
+
+// ---- the gated feed-forward block as one kernel (gdfn_fused.hip) -------------------------------------------------
+struct GdfnFusedW {          // device pointers into a WeightPool, in the kernel's lane-major packings
+  const float *win = nullptr, *bin = nullptr, *dwp = nullptr, *dwb = nullptr, *wout = nullptr, *bout = nullptr;
+  int C = 0, hidden = 0;
+};
+// true when launch_gdfn_fused takes the shape (channels, hidden width, plane size)
+bool gdfn_fused_supported(int C, int hidden, int H, int W);
+// Host arrays in the reference's layouts: LayerNorm weight / bias [C] (bias null: BiasFree), project_in [2 hidden][C],
+// dwconv [2 hidden][9], project_out [C][hidden], their biases or null.
+GdfnFusedW pack_upload_gdfn_fused(WeightPool& pool, int C, int hidden, const float* ln_w, const float* ln_b,
+                                  const float* w_in, const float* b_in, const float* w_dw, const float* b_dw,
+                                  const float* w_out, const float* b_out);
+// y = x + project_out(gelu(dw(T)[:h]) * dw(T)[h:]), T = project_in(LayerNorm(x)); x and y must not alias.
+void launch_gdfn_fused(const GdfnFusedW& w, TV x, TV y, int B, int H, int W, bool ln_center, hipStream_t s);
+
 }  // namespace jirf

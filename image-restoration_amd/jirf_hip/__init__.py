@@ -59,6 +59,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_double), C.POINTER(_i), _i, C.POINTER(_i)]),
     "jirf_op_conv1x1": (_i, [_fp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "jirf_op_ln_conv1x1": (_i, [_fp, _fp, _fp, _i, _vp, _fp, _i, _i, _i, _i, _vp]),
+    "jirf_op_gdfn": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "jirf_op_ln_conv1x1_static": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _vp]),
     "jirf_train_scratch_generation": (_l, []),
     "jirf_train_kernel_timing": (_i, [_i]),

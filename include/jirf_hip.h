@@ -137,6 +137,19 @@ int jirf_op_conv1x1(const float* x, const float* w_host, const float* bias_host,
  * call.  ln_kind 1 = WithBias, 2 = BiasFree (hint_arch.py:98-145). */
 int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int ln_kind,
                        const float* w_host, float* y, int B, int Cin, int Cout, int P, void* stream);
+/* The gated feed-forward branch of a Restormer-style block with its LayerNorm and residual
+ * (FeedForward.execute hint_arch.py:150-186 inside TransformerBlock.execute :429-433; the same module in
+ * fpro_arch.py:92-114):
+ *     y = x + project_out( gelu(d[:hidden]) * d[hidden:] ),  d = dwconv3x3(project_in(LayerNorm(x)))
+ * x, y [B,C,H,W] device, distinct buffers.  HOST arrays in the reference's layouts: ln_w, ln_b [C] (ln_kind 1 =
+ * WithBias, 2 = BiasFree: ln_b ignored), w_in [2 hidden][C], w_dw [2 hidden][3][3], w_out [C][hidden]; b_in
+ * [2 hidden], b_dw [2 hidden], b_out [C] or NULL (the `bias` option).  fused != 0: the one-kernel form, in which
+ * the hidden tensor never reaches device memory (C = 96, hidden <= 256, W >= 32; otherwise JIRF_EINVAL); fused == 0:
+ * the three launches used for every other shape (LayerNorm-GEMM, depthwise + gate, GEMM + residual).  Synchronises
+ * `stream`. */
+int jirf_op_gdfn(const float* x, float* y, int B, int C, int hidden, int H, int W, int ln_kind, const float* ln_w_host,
+                 const float* ln_b_host, const float* w_in_host, const float* b_in_host, const float* w_dw_host,
+                 const float* b_dw_host, const float* w_out_host, const float* b_out_host, int fused, void* stream);
 /* No counterpart in the reference.  jirf_op_ln_conv1x1 for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the packed
  * weights and, for Cin > 256, the per-pixel LayerNorm statistics live in a static device array of
@@ -158,8 +171,8 @@ int jirf_op_ln_conv1x1_static(const float* x, const float* ln_w, const float* ln
  * 0.5 v (1 + erf(v / sqrt 2)) (hint_arch.py:184,209,226; ast_arch.py:384,456-466; astv2_arch.py:139,184;
  * fpro_arch.py:39-44) through one branch-free polynomial + power of two for erfc instead of the C library's erff.
  * This scans EVERY float in [-hi, hi] on the device and returns maxima to out4_host (host, 4 doubles):
- * [0] |2^-(...) form - erfc(u / sqrt 2)| against float64, [1] |gelu - float64 gelu|, [2] the same in units of the
- * float spacing at the exact value, [3] |gelu - the erff form|.  Synchronises `stream`. */
+ * [0] |2^-(...) form - erfc(u / sqrt 2)| against float64, [1] |gelu - float64 gelu|, [2] the same for v >= 0 in units of
+ * the float spacing at the exact value, [3] |gelu - the erff form|.  Synchronises `stream`. */
 int jirf_op_gelu_error_scan(float hi, double* out4_host, void* stream);
 /* Dense 3x3, stride 1, zero pad 1 (hint_arch.py:441-448,459-466,479-486,648-655).
  * w_host [Cout,Cin,3,3].  mode 0: plain; 1: followed by pixel-unshuffle(2)

@@ -146,7 +146,8 @@ def test_layernorm_large_plane(kind, C):
 def test_gelu_over_every_float():
     """The kernels evaluate nn.GELU's erf form through one branch-free polynomial + power of two for erfc.  Scanned on
     the device over EVERY float in [-8.5, 8.5] (that is |x| <= 6 for erf(x) itself, x = v / sqrt 2) against float64:
-    the erfc value within 2e-7 absolute, gelu within 2.5 spacings of the exact value's float, and within 5e-7 of the
+    the erfc value within 2e-7 absolute, gelu within 5e-7 absolute (for v >= 0 within 2.5 spacings of the exact
+    value's float; for v < 0 gelu decays to zero and only the absolute error means anything), and within 1e-6 of the
     form on the C library's erff that it replaced.  A second scan up to 1e30 checks the tail (gelu(v) -> max(v, 0))."""
     out = (C.c_double * 4)()
     call("jirf_op_gelu_error_scan", 8.5, out, stream())
