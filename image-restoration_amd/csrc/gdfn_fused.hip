@@ -9,7 +9,7 @@
 // Line-buffer form.  A workgroup of eight waves owns a vertical strip of the image, 32 pixel columns wide (30
 // output columns + one halo column each side, so the 3x3 taps find their neighbours inside the strip), and rolls
 // down it one image row per step.  Wave w owns hidden channels 32 w .. 32 w + 31 of both halves of T for the
-// whole strip, and per step
+// whole strip, and per step (waves 4-7 in another order, see the kernel)
 //   1. forms row y + 1 of its 64 channels of T on the matrix cores (v_mfma_f32_32x32x2_f32: A = its rows of W_in
 //      from L2 in a lane-major packing, B = the normalised input row, shared by the eight waves through LDS);
 //      pixel columns sit on the MFMA column (lane) index, channels in the 16 accumulator registers;
@@ -166,12 +166,30 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
   }
   __syncthreads();
 
+  // The two waves that share a SIMD (w and w + 4) must not do the same kind of work at the same time: the three
+  // phases of a step - row of T (matrix), convolution + gate (vector), output product (matrix) - depend on each other
+  // inside a wave, and two waves in the same phase leave one of the two pipes idle.  So the halves of the workgroup
+  // run the same step in a different order, one output row apart:
+  //   waves 0-3   row yi of T,  then convolution + product of output row yi - 1
+  //   waves 4-7   convolution + product of output row yi - 2,  then row yi of T
+  // (either order needs three ring rows).  Their partial tiles of one output row therefore arrive a step apart: the
+  // reducing threads keep the sum over waves 0-3 in registers for one step and finish the row when waves 4-7
+  // deliver theirs.  The sum is taken in a fixed order either way.
+  const bool late = wave >= 4;
+  f32x2 carry[3];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) carry[mt] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { T[k][0][r] = 0.f; T[k][1][r] = 0.f; }
   auto step = [&](auto slot_tag, auto out_tag, int yi) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_tag)::value;          // ring slot of row yi; yi - 1 in (S + 2) % 3, yi - 2 in (S + 1) % 3
     constexpr int SM = (S + 2) % 3, SO = (S + 1) % 3;
-    constexpr bool has_out = decltype(out_tag)::value;    // false for the two steps that only fill the ring
-    const bool row_in = yi >= 0 && yi < H;
-    const int yo = yi - 1;
+
+    const bool row_in = yi >= 0 && yi < H && yi <= ry1;
+    const int yo = yi - 2;                                // the row finished in this step
+    const bool fin = yo >= ry0, out_early = yi - 1 >= ry0 && yi - 1 < ry1;
     // Every weight word below is the same in every step, so the compiler would read all of them once, ahead of the
     // row loop, into some four hundred registers, and spill the ring to make room.  An offset it cannot see through
     // (always 0) ties each read to its own step.
@@ -185,6 +203,14 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
     const int yn = yi + 1;
     const bool next_in = yn <= ry1 && yn < H;           // the next row exists: normalise it during this step
 
+    // the next input row is requested here, behind the last weight words of the matrix phase and in front of the
+    // convolution, which reads LDS only: the vector-memory counter is in order, so whatever is requested behind these
+    // loads waits for them too
+    float lnv[6];
+    float res[3][2];
+    if (next_in) ln_issue(yn, lnv);
+
+    if (!late) {
     // ---- 1. row yi of T ----
     if (row_in) {
       f32x16 a1, a2;
@@ -195,15 +221,22 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
         for (int i = 0; i < 4; ++i) { a1[4 * q + i] = b1[i]; a2[4 * q + i] = b2[i]; }
       }
       const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(Xh + (yi & 1) * GF_XH) + half * 32 + l31;
+      // weight words two groups ahead and the normalised row one group ahead, in program order (see the output
+      // product below for why)
+      f32x4 wa0 = win_w[0], wb0 = win_w[GF_G * 64], wa1 = win_w[64], wb1 = win_w[(GF_G + 1) * 64];
+      f32x4 bq0 = bp[0];
 #pragma unroll
       for (int g = 0; g < GF_G; ++g) {
-        const f32x4 bq = bp[g * 64];
-        const f32x4 w1 = win_w[g * 64], w2 = win_w[(GF_G + g) * 64];
+        f32x4 wa2 = wa1, wb2 = wb1, bq1 = bq0;
+        if (g + 2 < GF_G) { wa2 = win_w[(g + 2) * 64]; wb2 = win_w[(GF_G + g + 2) * 64]; }
+        if (g + 1 < GF_G) bq1 = bp[(g + 1) * 64];
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j], bq[j], a1, 0, 0, 0);
-          a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[j], bq[j], a2, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0[j], bq0[j], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb0[j], bq0[j], a2, 0, 0, 0);
         }
+        wa0 = wa1; wb0 = wb1; wa1 = wa2; wb1 = wb2; bq0 = bq1;
       }
       if (edge) {
 #pragma unroll
@@ -216,14 +249,7 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
       for (int r = 0; r < 16; ++r) { T[S][0][r] = 0.f; T[S][1][r] = 0.f; }
     }
 
-    // the next input row is requested here, behind the last weight words of the matrix phase and in front of the
-    // convolution, which reads LDS only: the vector-memory counter is in order, so whatever is requested behind these
-    // loads waits for them too
-    float lnv[6];
-    float res[3][2];
-    if (next_in) ln_issue(yn, lnv);
-
-    if constexpr (has_out) {
+    if (out_early) {
       // ---- 2. depthwise 3x3 of row yo (rows yo - 1, yo, yo + 1 = slots SO, SM, S) and the gate ----
       f32x16 G;
 #pragma unroll
@@ -235,12 +261,20 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
           // front and the register allocator evicts the ring to scratch to hold them
           asm volatile("" ::: "memory");
           d[t] = dwb_w[(t * 4 + q) * 2];
+          f32x4 wrow[3], wnext[3];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) wrow[kx] = dw_w[((t * 9 + kx) * 4 + q) * 2];
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
+            if (ky < 2) {
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) wnext[kx] = dw_w[((t * 9 + (ky + 1) * 3 + kx) * 4 + q) * 2];
+            }
+            asm volatile("" ::: "memory");
             const f32x16& src = ky == 0 ? T[SO][t] : ky == 1 ? T[SM][t] : T[S][t];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const f32x4 wv = dw_w[((t * 9 + ky * 3 + kx) * 4 + q) * 2];
+              const f32x4 wv = wrow[kx];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const float c = src[4 * q + i];
@@ -248,19 +282,27 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
                 d[t][i] = fmaf(wv[i], sh, d[t][i]);
               }
             }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) wrow[kx] = wnext[kx];
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) G[4 * q + i] = gelu_fast(d[0][i]) * d[1][i];
 
       }
-      // the residual of row yo: requested behind the convolution's registers, in front of the 48 MFMAs
+      // the residual of the row finished in this step (row 0 when there is none yet: read and not used - a branch
+      // here would cut the step into blocks, across which the register allocator does much worse): requested behind
+      // the convolution's registers, in front of the 48 MFMAs
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          res[mt][e] = xb[(long)(32 * mt + rd_row + e) * P + (long)yo * W + (rd_ok ? rd_col : 0)];
+          res[mt][e] = xb[(long)(32 * mt + rd_row + e) * P + (long)max(yo, 0) * W + (rd_ok ? rd_col : 0)];
       // ---- 3. this wave's share of W_out G: 16 k-steps per 32 output channels ----
+      // (the weight words two groups ahead, in program order: where the registers are this tight the compiler keeps
+      // the order it is given, and a load placed next to its use waits a whole L2 round trip in front of every four
+      // matrix instructions)
+      f32x4 wo0 = wout_w[0], wo1 = wout_w[64];
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt) {
         f32x16 o;
@@ -268,9 +310,13 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 wo = wout_w[(mt * 4 + q) * 64];
+          f32x4 wo2 = wo1;
+          if (mt * 4 + q + 2 < 12) wo2 = wout_w[(mt * 4 + q + 2) * 64];
+          asm volatile("" ::: "memory");
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(wo[i], G[4 * q + i], o, 0, 0, 0);
+          for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(wo0[i], G[4 * q + i], o, 0, 0, 0);
+          wo0 = wo1;
+          wo1 = wo2;
         }
         f32x4* __restrict__ pd = reinterpret_cast<f32x4*>(part) + ((wave * 3 + mt) * 4) * 64 + lane;
 #pragma unroll
@@ -278,43 +324,169 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
       }
     }
 
+    if (!out_early && fin) {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          res[mt][e] = xb[(long)(32 * mt + rd_row + e) * P + (long)yo * W + (rd_ok ? rd_col : 0)];
+    }
+    } else {
+    if (fin) {
+      // ---- 2. depthwise 3x3 of row yo (rows yo - 1, yo, yo + 1 = slots SO, SM, S) and the gate ----
+      f32x16 G;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 d[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          // a fence for the compiler only: left alone the scheduler requests all 72 weight words of the row up
+          // front and the register allocator evicts the ring to scratch to hold them
+          asm volatile("" ::: "memory");
+          d[t] = dwb_w[(t * 4 + q) * 2];
+          f32x4 wrow[3], wnext[3];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) wrow[kx] = dw_w[((t * 9 + kx) * 4 + q) * 2];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            if (ky < 2) {
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) wnext[kx] = dw_w[((t * 9 + (ky + 1) * 3 + kx) * 4 + q) * 2];
+            }
+            asm volatile("" ::: "memory");
+            const f32x16& src = ky == 0 ? T[S][t] : ky == 1 ? T[SO][t] : T[SM][t];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const f32x4 wv = wrow[kx];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float c = src[4 * q + i];
+                const float sh = kx == 0 ? dpp_from_left(c) : kx == 2 ? dpp_from_right(c) : c;
+                d[t][i] = fmaf(wv[i], sh, d[t][i]);
+              }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) wrow[kx] = wnext[kx];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G[4 * q + i] = gelu_fast(d[0][i]) * d[1][i];
+
+      }
+      // the residual of the row finished in this step (row 0 when there is none yet: read and not used - a branch
+      // here would cut the step into blocks, across which the register allocator does much worse): requested behind
+      // the convolution's registers, in front of the 48 MFMAs
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          res[mt][e] = xb[(long)(32 * mt + rd_row + e) * P + (long)max(yo, 0) * W + (rd_ok ? rd_col : 0)];
+      // ---- 3. this wave's share of W_out G: 16 k-steps per 32 output channels ----
+      // (the weight words two groups ahead, in program order: where the registers are this tight the compiler keeps
+      // the order it is given, and a load placed next to its use waits a whole L2 round trip in front of every four
+      // matrix instructions)
+      f32x4 wo0 = wout_w[0], wo1 = wout_w[64];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 wo2 = wo1;
+          if (mt * 4 + q + 2 < 12) wo2 = wout_w[(mt * 4 + q + 2) * 64];
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(wo0[i], G[4 * q + i], o, 0, 0, 0);
+          wo0 = wo1;
+          wo1 = wo2;
+        }
+        f32x4* __restrict__ pd = reinterpret_cast<f32x4*>(part) + ((wave * 3 + mt) * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pd[q * 64] = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+      }
+    }
+
+    // ---- 1. row yi of T ----
+    if (row_in) {
+      f32x16 a1, a2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b1 = bin_w[(0 * 4 + q) * 2], b2 = bin_w[(1 * 4 + q) * 2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a1[4 * q + i] = b1[i]; a2[4 * q + i] = b2[i]; }
+      }
+      const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(Xh + (yi & 1) * GF_XH) + half * 32 + l31;
+      // weight words two groups ahead and the normalised row one group ahead, in program order (see the output
+      // product below for why)
+      f32x4 wa0 = win_w[0], wb0 = win_w[GF_G * 64], wa1 = win_w[64], wb1 = win_w[(GF_G + 1) * 64];
+      f32x4 bq0 = bp[0];
+#pragma unroll
+      for (int g = 0; g < GF_G; ++g) {
+        f32x4 wa2 = wa1, wb2 = wb1, bq1 = bq0;
+        if (g + 2 < GF_G) { wa2 = win_w[(g + 2) * 64]; wb2 = win_w[(GF_G + g + 2) * 64]; }
+        if (g + 1 < GF_G) bq1 = bp[(g + 1) * 64];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0[j], bq0[j], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb0[j], bq0[j], a2, 0, 0, 0);
+        }
+        wa0 = wa1; wb0 = wb1; wa1 = wa2; wb1 = wb2; bq0 = bq1;
+      }
+      if (edge) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a1[r] *= colmask; a2[r] *= colmask; }
+      }
+      T[S][0] = a1;
+      T[S][1] = a2;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { T[S][0][r] = 0.f; T[S][1][r] = 0.f; }
+    }
+
+    }
     if (next_in) ln_finish(lnv, yn & 1);
     __syncthreads();
 
-    if constexpr (has_out) {
-      // ---- add the eight partial tiles in wave order, the residual, and store row yo ----
+    // the partial tiles: waves 0-3 delivered row yi - 1 (kept for one step), waves 4-7 row yi - 2 (finished now)
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt) {
-        f32x2 s = rd_src[(0 * 3 + mt) * 4 * 64 * 2];
+    for (int mt = 0; mt < 3; ++mt) {
+      f32x2 early = rd_src[(0 * 3 + mt) * 4 * 64 * 2];
 #pragma unroll
-        for (int w = 1; w < GF_NW; ++w) s += rd_src[(w * 3 + mt) * 4 * 64 * 2];
+      for (int w = 1; w < 4; ++w) early += rd_src[(w * 3 + mt) * 4 * 64 * 2];
+      if (fin) {
+        f32x2 sl = rd_src[(4 * 3 + mt) * 4 * 64 * 2];
+#pragma unroll
+        for (int w = 5; w < GF_NW; ++w) sl += rd_src[(w * 3 + mt) * 4 * 64 * 2];
+        sl += carry[mt];
         if (rd_ok) {
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int co = 32 * mt + rd_row + e;
-            float v = s[e] + res[mt][e];
+            float v = sl[e] + res[mt][e];
             if (a.bout) v += a.bout[co];
             yb[(long)co * P + (long)yo * W + rd_col] = v;
           }
         }
       }
+      carry[mt] = early;
     }
     __syncthreads();
   };
 
-  step(std::integral_constant<int, 0>{}, std::false_type{}, ry0 - 1);
-  step(std::integral_constant<int, 1>{}, std::false_type{}, ry0);
-  for (int yi = ry0 + 1;; yi += 3) {                      // ry1 > ry0: at least one output row
-    step(std::integral_constant<int, 2>{}, std::true_type{}, yi);
-    if (yi + 1 > ry1) break;
-    step(std::integral_constant<int, 0>{}, std::true_type{}, yi + 1);
-    if (yi + 2 > ry1) break;
-    step(std::integral_constant<int, 1>{}, std::true_type{}, yi + 2);
-    if (yi + 3 > ry1) break;
+  for (int yi = ry0 - 1;; yi += 3) {
+    step(std::integral_constant<int, 0>{}, std::false_type{}, yi);
+    if (yi + 1 > ry1 + 1) break;
+    step(std::integral_constant<int, 1>{}, std::false_type{}, yi + 1);
+    if (yi + 2 > ry1 + 1) break;
+    step(std::integral_constant<int, 2>{}, std::false_type{}, yi + 2);
+    if (yi + 3 > ry1 + 1) break;
   }
 }
 
 DynLdsOnce g_gdfn_lds;
+
 
 }  // namespace
 
@@ -376,6 +548,7 @@ GdfnFusedW pack_upload_gdfn_fused(WeightPool& pool, int C, int hidden, const flo
   r.bout = b_out ? pool.upload(b_out, (size_t)C) : nullptr;
   return r;
 }
+
 
 void launch_gdfn_fused(const GdfnFusedW& w, TV x, TV y, int B, int H, int W, bool ln_center, hipStream_t s) {
   JIRF_REQUIRE(gdfn_fused_supported(w.C, w.hidden, H, W), JIRF_EINVAL, "fused GDFN: %dx%d with C=%d hidden=%d is not built",
