@@ -265,6 +265,11 @@ struct WinAttnArgs {
 };
 void launch_window_attention(const WinAttnArgs& a, hipStream_t s);
 
+// exp(x) for the softmax kernels: one v_exp_f32 on x * log2(e).  The product's rounding adds |x| * 6e-8 to the
+// relative error (arguments here are score - row maximum, in [-100, 0]); arguments below -87 give 0 or a denormal,
+// as expf does.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 // ---- kernel accounting -----------------------------------------------------------------------
 struct KernelClock;
 KernelClock* current_clock();

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void cross_win_attn_kernel(const float* __rest
   float sum = 0.f;
 #pragma unroll
   for (int m = 0; m < 64; ++m) {
-    sc[m] = expf(sc[m] - mx);
+    sc[m] = fast_exp(sc[m] - mx);
     sum += sc[m];
   }
   const float inv = 1.0f / sum;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void cross_win_attn_mfma_kernel(const float
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[mt][nt][r] = expf(S[mt][nt][r] - mx);
+        S[mt][nt][r] = fast_exp(S[mt][nt][r] - mx);
         sum += S[mt][nt][r];
       }
     sum += __shfl_xor(sum, 32);

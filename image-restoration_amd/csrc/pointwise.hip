@@ -196,6 +196,62 @@ __global__ __launch_bounds__(256) void layernorm_regs_kernel(const float* __rest
   }
 }
 
+// Small planes with many channels (the deep levels of a single image): the forms above walk a wave's channel slice
+// one load after another, C / 4 deep and three times over, on a handful of workgroups.  Here a workgroup owns 16
+// adjacent pixels and deals the channels over 16 thread rows, so a thread holds C / 16 values (all of its loads in
+// flight together, x read once) and the statistics meet in LDS.  Two-pass mean / variance as everywhere else.
+template <int KIND, int NCH>
+__global__ __launch_bounds__(256) void layernorm_small_kernel(const float* __restrict__ x, long x_bs,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ y, long y_bs, int C, int P,
+                                                              float* __restrict__ mu_out, float* __restrict__ rstd_out) {
+  __shared__ float part[2][16][17];
+  const int px = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int p = blockIdx.x * 16 + px, b = blockIdx.y;
+  const bool ok = p < P;
+  const float* __restrict__ xp = x + (long)b * x_bs + (ok ? p : 0);
+  float v[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) v[i] = xp[(long)min(cl + 16 * i, C - 1) * P];   // clamped: no predicate around the load
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (cl + 16 * i < C) sum += v[i];
+  part[0][cl][px] = sum;
+  __syncthreads();
+  float mu = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) mu += part[0][j][px];
+  mu /= (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (cl + 16 * i < C) sq = fmaf(v[i] - mu, v[i] - mu, sq);
+  part[1][cl][px] = sq;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) var += part[1][j][px];
+  const float rstd = 1.0f / sqrtf(var / (float)C + 1e-5f);
+  if (!ok) return;
+  if constexpr (KIND == 0) {   // statistics only
+    if (cl == 0) {
+      mu_out[(long)b * P + p] = mu;
+      rstd_out[(long)b * P + p] = rstd;
+    }
+    return;
+  }
+  float* __restrict__ yp = y + (long)b * y_bs + p;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = cl + 16 * i;
+    if (c >= C) break;
+    if constexpr (KIND == 1) yp[(long)c * P] = (v[i] - mu) * rstd * w[c] + bias[c];
+    else yp[(long)c * P] = v[i] * rstd * w[c];
+  }
+}
+
 void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, int P, int kind,
                       hipStream_t s) {
   JIRF_REQUIRE(kind == 1 || kind == 2, JIRF_EINVAL, "layernorm: kind %d", kind);
@@ -204,7 +260,18 @@ void launch_layernorm(TV x, const float* w, const float* b, TV y, int B, int C, 
   const bool vec = P % 4 == 0 && x.bs % 4 == 0 && y.bs % 4 == 0 && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(y.p) & 15) == 0 && (long)B * P >= 256L * 1024;
   const dim3 block(256);
-  if (vec && C <= 96) {
+  if ((long)B * P <= 16384 && C >= 128 && C <= 1024) {
+    const dim3 grid((P + 15) / 16, B);
+#define JIRF_LN_SMALL(N)                                                                                              \
+  do {                                                                                                                \
+    if (kind == 1) hipLaunchKernelGGL((layernorm_small_kernel<1, N>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P, nullptr, nullptr); \
+    else hipLaunchKernelGGL((layernorm_small_kernel<2, N>), grid, block, 0, s, x.p, x.bs, w, b, y.p, y.bs, C, P, nullptr, nullptr);       \
+  } while (0)
+    if (C <= 256) JIRF_LN_SMALL(16);
+    else if (C <= 512) JIRF_LN_SMALL(32);
+    else JIRF_LN_SMALL(64);
+#undef JIRF_LN_SMALL
+  } else if (vec && C <= 96) {
     const dim3 grid((P + 255) / 256, B);
 #define JIRF_LN_REGS(N)                                                                                              \
   do {                                                                                                               \
@@ -265,7 +332,16 @@ __global__ __launch_bounds__(256) void ln_stats_split_kernel(const float* __rest
 
 void launch_ln_stats(TV x, float* mu, float* rstd, int B, int C, int P, hipStream_t s) {
   Scope sc(intern_label("ln_stats C%d P%d", C, P), 5.0 * B * (double)C * P, 4.0 * B * (double)P * (C + 2), s);
-  if ((long)B * P <= 256 * 1024) {
+  if ((long)B * P <= 16384 && C >= 128 && C <= 1024) {
+    const dim3 grid((P + 15) / 16, B), block(256);
+    float* const none = nullptr;
+    if (C <= 256)
+      hipLaunchKernelGGL((layernorm_small_kernel<0, 16>), grid, block, 0, s, x.p, x.bs, none, none, none, 0L, C, P, mu, rstd);
+    else if (C <= 512)
+      hipLaunchKernelGGL((layernorm_small_kernel<0, 32>), grid, block, 0, s, x.p, x.bs, none, none, none, 0L, C, P, mu, rstd);
+    else
+      hipLaunchKernelGGL((layernorm_small_kernel<0, 64>), grid, block, 0, s, x.p, x.bs, none, none, none, 0L, C, P, mu, rstd);
+  } else if ((long)B * P <= 256 * 1024) {
     hipLaunchKernelGGL(ln_stats_split_kernel, dim3((P + 63) / 64, B), dim3(256), 0, s, x.p, x.bs, mu, rstd, C, P);
   } else {
     hipLaunchKernelGGL(layernorm_kernel<0>, dim3((P + 255) / 256, B), dim3(256), 0, s, x.p, x.bs, nullptr,

@@ -988,11 +988,15 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
           mx = fmaxf(mx, sc);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float ex[2][16];   // each exponential once
       float sum = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum += expf(S[mt][r] - mx);
+        for (int r = 0; r < 16; ++r) {
+          ex[mt][r] = fast_exp(S[mt][r] - mx);
+          sum += ex[mt][r];
+        }
       sum += __shfl_xor(sum, 32);
       const float inv = 1.0f / sum;
       float D = 0.f, t1 = 0.f;
@@ -1000,8 +1004,9 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float sc = S[mt][r], rl = fmaxf(sc, 0.f);
-          D = fmaf(dA[mt][r], expf(sc - mx) * inv, D);
+          const float rl = fmaxf(S[mt][r], 0.f);
+          ex[mt][r] *= inv;
+          D = fmaf(dA[mt][r], ex[mt][r], D);
           t1 = fmaf(dA[mt][r], rl * rl, t1);
         }
       D += __shfl_xor(D, 32);
@@ -1014,8 +1019,8 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float sc = S[mt][r], rl = fmaxf(sc, 0.f), d = dA[mt][r];
-          S[mt][r] = w0 * (expf(sc - mx) * inv) * (d - D) + 2.0f * w1 * rl * d;   // dS^T
+          const float rl = fmaxf(S[mt][r], 0.f), d = dA[mt][r];
+          S[mt][r] = w0 * ex[mt][r] * (d - D) + 2.0f * w1 * rl * d;   // dS^T
         }
       // dQ^T[e][n] = sum_m K[m][e] dS^T[m][n]
       f32x16 O;
@@ -1069,7 +1074,7 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
             const int rid_m = __shfl(rid_tok, m);
             if (rid_m != rid_n) sc += -100.0f;
           }
-          const float p0 = expf(sc - mx) * inv, rl = fmaxf(sc, 0.f), d = dA[mt][r];
+          const float p0 = fast_exp(sc - mx) * inv, rl = fmaxf(sc, 0.f), d = dA[mt][r];
           S[mt][r] = w0 * p0 + w1 * rl * rl;                        // A[n][m]
           dA[mt][r] = w0 * p0 * (d - D) + 2.0f * w1 * rl * d;        // dS[n][m]
         }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_kernel(const WinAttnArgs a, i
   for (int e = 0; e < WA_D; ++e) vs[lane * WA_LD + e] = vreg[e];
   float sum = 0.f;
 #pragma unroll
-  for (int m = 0; m < WA_N; ++m) sum += expf(sc[m] - mx);
+  for (int m = 0; m < WA_N; ++m) sum += fast_exp(sc[m] - mx);
   const float inv = 1.0f / sum;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_kernel(const WinAttnArgs a, i
 #pragma unroll
   for (int m = 0; m < WA_N; ++m) {
     const float r = fmaxf(sc[m], 0.f);
-    const float p = (expf(sc[m] - mx) * inv) * a.w_softmax + (r * r) * a.w_relu2;
+    const float p = (fast_exp(sc[m] - mx) * inv) * a.w_softmax + (r * r) * a.w_relu2;
     const float4* __restrict__ vr = reinterpret_cast<const float4*>(&vs[m * WA_LD]);
 #pragma unroll
     for (int e4 = 0; e4 < WA_D / 4; ++e4) {
@@ -166,12 +166,14 @@ __global__ __launch_bounds__(256, 3) void win_attn_mfma_kernel(const WinAttnArgs
   __shared__ float Ts[4][232];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int task = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // neighbouring windows share an XCD's L2
-  if (task >= n_tasks) return;   // whole wave exits together; only wave-level synchronisation below
+  // The four waves of a workgroup take four windows that are neighbours along x, for the same head: a window row is
+  // 32 bytes of a 128-byte line, and the four waves ask for the four quarters of each line at about the same time.
   const int H = a.H, W = a.W, heads = a.heads;
   const int nwx = W >> 3, nW = (H >> 3) * nwx;
   const long P = (long)H * W;
-  const int gw = task / heads, h = task - gw * heads;
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int gw = (blk / heads) * 4 + wave, h = blk % heads;
+  if (gw * heads >= n_tasks) return;   // whole wave exits together; only wave-level synchronisation below
   const int img = gw / nW, w = gw - img * nW;
   const int span = a.coupled ? a.B * nW : nW;
   const int j = (a.coupled ? gw : w) * heads + h;
@@ -268,20 +270,24 @@ __global__ __launch_bounds__(256, 3) void win_attn_mfma_kernel(const WinAttnArgs
         mx = fmaxf(mx, sc);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // each exponential once: kept in registers between the row sum and the mix
+    float ex[2][16];
     float sum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sum += expf(S[mt][nt][r] - mx);
+      for (int r = 0; r < 16; ++r) {
+        ex[mt][r] = fast_exp(S[mt][nt][r] - mx);
+        sum += ex[mt][r];
+      }
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    const float inv_soft = w_soft / sum;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float sc = S[mt][nt][r];
-        const float rl = fmaxf(sc, 0.f);
-        S[mt][nt][r] = (expf(sc - mx) * inv) * w_soft + (rl * rl) * w_relu;
+        const float rl = fmaxf(S[mt][nt][r], 0.f);
+        S[mt][nt][r] = fmaf(ex[mt][r], inv_soft, (rl * rl) * w_relu);
       }
   }
 
@@ -322,7 +328,7 @@ void launch_window_attention(const WinAttnArgs& a, hipStream_t s) {
   if (valu)
     hipLaunchKernelGGL(win_attn_kernel, dim3((n_tasks + 3) / 4), dim3(256), 0, s, a, n_tasks);
   else
-    hipLaunchKernelGGL(win_attn_mfma_kernel, dim3((n_tasks + 3) / 4), dim3(256), 0, s, a, n_tasks);
+    hipLaunchKernelGGL(win_attn_mfma_kernel, dim3((n_tasks / a.heads + 3) / 4 * a.heads), dim3(256), 0, s, a, n_tasks);
   JIRF_HIP_CHECK(hipGetLastError());
 }
 
