@@ -920,20 +920,24 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       return (long)y * W + x;
     };
     // ---- operand fragments: token t2 * 32 + l31, channels 2 s + half -------------------------------------------
+    // (addresses as a wave-uniform base + a 32-bit byte offset per lane: one register per token instead of a 64-bit
+    //  pointer per load, which is what pushed this kernel's 230 loads and stores over the register file)
+    auto at = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+    const float* __restrict__ kb = a.k + (long)img_k * a.qkv_bs + (long)(hk * 32) * P;
+    const float* __restrict__ qb = a.q + (long)img * a.qkv_bs + (long)(h * 32) * P;
+    const float* __restrict__ vb = a.v + (long)img * a.qkv_bs + (long)(h * 32) * P;
+    const float* __restrict__ gb = a.dout + (long)img * a.dout_bs + (long)(h * 32) * P;
     float kf[2][16], qf[2][16], vf[2][16], gf[2][16];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-      const long pq = pixel(w, t2 * 32 + l31), pk = pixel(wk, t2 * 32 + l31);
-      const float* __restrict__ kp = a.k + (long)img_k * a.qkv_bs + (long)(hk * 32 + half) * P + pk;
-      const float* __restrict__ qp = a.q + (long)img * a.qkv_bs + (long)(h * 32 + half) * P + pq;
-      const float* __restrict__ vp = a.v + (long)img * a.qkv_bs + (long)(h * 32 + half) * P + pq;
-      const float* __restrict__ gp = a.dout + (long)img * a.dout_bs + (long)(h * 32 + half) * P + pq;
+      const unsigned oq = (unsigned)((long)half * P + pixel(w, t2 * 32 + l31)) * 4u;
+      const unsigned ok = (unsigned)((long)half * P + pixel(wk, t2 * 32 + l31)) * 4u;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        kf[t2][s] = kp[(long)(2 * s) * P];
-        qf[t2][s] = qp[(long)(2 * s) * P] * a.scale;
-        vf[t2][s] = vp[(long)(2 * s) * P];
-        gf[t2][s] = gp[(long)(2 * s) * P];
+        kf[t2][s] = at(kb + (long)(2 * s) * P, ok);
+        qf[t2][s] = at(qb + (long)(2 * s) * P, oq) * a.scale;
+        vf[t2][s] = at(vb + (long)(2 * s) * P, oq);
+        gf[t2][s] = at(gb + (long)(2 * s) * P, oq);
       }
     }
     __syncthreads();   // the previous window's tiles are no longer read
@@ -963,12 +967,16 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { S[mt][r] = 0.f; dA[mt][r] = 0.f; }
+      // the query-side fragments (scaled q, dO) are read back from their staged tiles: holding them in registers
+      // next to the key-side ones overflowed the register file into scratch
+      const float* __restrict__ qs_frag = &Qs[(nt * 32 + l31) * WB_LD + half];
+      const float* __restrict__ gs_frag = &Gs[(nt * 32 + l31) * WB_LD + half];
 #pragma unroll
       for (int s = 0; s < 16; ++s)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          S[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[mt][s], qf[nt][s], S[mt], 0, 0, 0);
-          dA[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[mt][s], gf[nt][s], dA[mt], 0, 0, 0);
+          S[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[mt][s], qs_frag[2 * s], S[mt], 0, 0, 0);
+          dA[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[mt][s], gs_frag[2 * s], dA[mt], 0, 0, 0);
         }
       const int n = nt * 32 + l31;
       const int ny = n >> 3, nx = n & 7;
@@ -1034,9 +1042,13 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
           O = __builtin_amdgcn_mfma_f32_32x32x2f32(av, S[mt][r], O, 0, 0, 0);
           if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the LDS reads from being hoisted in bulk)
         }
-      float* __restrict__ op = a.dq + (long)img * a.dqkv_bs + (long)(h * 32 + 4 * half) * P + pixel(w, nt * 32 + l31);
+      {
+        float* __restrict__ ob = a.dq + (long)img * a.dqkv_bs + (long)(h * 32) * P;
+        const unsigned oo = (unsigned)((long)(4 * half) * P + pixel(w, nt * 32 + l31)) * 4u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) op[(long)((r & 3) + 8 * (r >> 2)) * P] = O[r] * a.scale;
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(ob + (long)((r & 3) + 8 * (r >> 2)) * P) + oo) = O[r] * a.scale;
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();   // the statistics are in LDS
@@ -1053,12 +1065,14 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { S[mt][r] = 0.f; dA[mt][r] = 0.f; }
+      const float* __restrict__ qs_frag = &Qs[(nt * 32 + l31) * WB_LD + half];
+      const float* __restrict__ gs_frag = &Gs[(nt * 32 + l31) * WB_LD + half];
 #pragma unroll
       for (int s = 0; s < 16; ++s)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          S[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[nt][s], kf[mt][s], S[mt], 0, 0, 0);
-          dA[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[nt][s], vf[mt][s], dA[mt], 0, 0, 0);
+          S[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qs_frag[2 * s], kf[mt][s], S[mt], 0, 0, 0);
+          dA[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gs_frag[2 * s], vf[mt][s], dA[mt], 0, 0, 0);
         }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1096,12 +1110,14 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const WinBwdArgs a) {
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      float* __restrict__ vp = a.dv + (long)img * a.dqkv_bs + (long)(h * 32 + 4 * half) * P + pixel(w, mt * 32 + l31);
-      float* __restrict__ kp = a.dk + (long)img_k * a.dqkv_bs + (long)(hk * 32 + 4 * half) * P + pixel(wk, mt * 32 + l31);
+      float* __restrict__ dvb = a.dv + (long)img * a.dqkv_bs + (long)(h * 32) * P;
+      float* __restrict__ dkb = a.dk + (long)img_k * a.dqkv_bs + (long)(hk * 32) * P;
+      const unsigned ov = (unsigned)((long)(4 * half) * P + pixel(w, mt * 32 + l31)) * 4u;
+      const unsigned ok = (unsigned)((long)(4 * half) * P + pixel(wk, mt * 32 + l31)) * 4u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        vp[(long)((r & 3) + 8 * (r >> 2)) * P] = OV[mt][r];
-        kp[(long)((r & 3) + 8 * (r >> 2)) * P] = OK[mt][r];
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(dvb + (long)((r & 3) + 8 * (r >> 2)) * P) + ov) = OV[mt][r];
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(dkb + (long)((r & 3) + 8 * (r >> 2)) * P) + ok) = OK[mt][r];
       }
     }
     // ---- table gradient: the dS tile is in LDS, one lane per table entry ----------------------------------------------
