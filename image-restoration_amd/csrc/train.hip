@@ -602,17 +602,42 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
 // pointer offset plus that tensor's batch stride).
 // forward   mode 0: y = gelu(pre)                    (after linear1, ast_arch.py:384,456; after the depthwise 3x3 of LeFF)
 //           mode 1: y = gelu(pre) * x2               (the FRFN gate, ast_arch.py:507-510)
+//           mode 3: y = gelu(pre) * gelu(x2)         (the same gate fed linear1's raw second half: the GELU after
+//                                                     linear1 is then applied only where the depthwise 3x3 needs it)
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ pre, long pre_bs,
                                                        const float* __restrict__ x2, long x2_bs, float* __restrict__ y,
                                                        long y_bs, long n_img, int mode) {
   const int b = blockIdx.y;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_img; i += (long)gridDim.x * 256) {
     const float a = gelu_f(pre[(long)b * pre_bs + i]);
-    y[(long)b * y_bs + i] = mode ? a * x2[(long)b * x2_bs + i] : a;
+    if (mode == 0) y[(long)b * y_bs + i] = a;
+    else if (mode == 1) y[(long)b * y_bs + i] = a * x2[(long)b * x2_bs + i];
+    else y[(long)b * y_bs + i] = a * gelu_f(x2[(long)b * x2_bs + i]);
+  }
+}
+// the same, four adjacent elements per thread as one 16-byte access per tensor (n_img % 4 == 0, 16-byte aligned rows)
+__global__ __launch_bounds__(256) void gelu_fwd4_kernel(const float* __restrict__ pre, long pre_bs,
+                                                        const float* __restrict__ x2, long x2_bs, float* __restrict__ y,
+                                                        long y_bs, long n4, int mode) {
+  const int b = blockIdx.y;
+  const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pre + (long)b * pre_bs);
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x2 ? x2 + (long)b * x2_bs : pre);
+  float4* __restrict__ y4 = reinterpret_cast<float4*>(y + (long)b * y_bs);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 a = p4[i];
+    float4 r = make_float4(gelu_f(a.x), gelu_f(a.y), gelu_f(a.z), gelu_f(a.w));
+    if (mode != 0) {
+      float4 g = x4[i];
+      if (mode == 3) g = make_float4(gelu_f(g.x), gelu_f(g.y), gelu_f(g.z), gelu_f(g.w));
+      r = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
+    }
+    y4[i] = r;
   }
 }
 // backward  mode 0: dxa = dy * gelu'(pre)
 //           mode 1: y = gelu(a) * b with a = pre, b = x2:  dxa = dy * b * gelu'(a),  dxb = dy * gelu(a)
+//           mode 3: y = gelu(a) * gelu(b) with a = pre, b = x2 (both raw):  dxa = dy * gelu(b) * gelu'(a),
+//                   dxb = dy * gelu(a) * gelu'(b)
 //           mode 2: LeakyReLU(0.01) (ast_arch.py:563 input_proj), pre = the activation's OUTPUT (same sign as its
 //                   input): dxa = dy * (pre > 0 ? 1 : 0.01)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ pre, long pre_bs,
@@ -629,6 +654,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
       const float bv = x2[(long)b * x2_bs + i];
       dxa[(long)b * dxa_bs + i] = g * bv * gelu_grad_f(a);
       dxb[(long)b * dxb_bs + i] = g * gelu_f(a);
+    } else if (mode == 3) {
+      const float br = x2[(long)b * x2_bs + i];
+      dxa[(long)b * dxa_bs + i] = g * gelu_f(br) * gelu_grad_f(a);
+      dxb[(long)b * dxb_bs + i] = g * gelu_f(a) * gelu_grad_f(br);
     } else {
       dxa[(long)b * dxa_bs + i] = a > 0.f ? g : 0.01f * g;
     }
@@ -1635,12 +1664,18 @@ int jirf_train_layernorm_bwd(const float* x, long x_bs, const float* dy, long dy
 int jirf_train_gelu(const float* pre, long pre_bs, const float* x2, long x2_bs, float* y, long y_bs, int B, long n_img,
                     int mode, void* stream) {
   return guarded_t([&] {
-    JIRF_REQUIRE(pre && y && B > 0 && n_img > 0 && (mode == 0 || (mode == 1 && x2)), JIRF_EINVAL, "train_gelu: bad arguments");
+    JIRF_REQUIRE(pre && y && B > 0 && n_img > 0 && (mode == 0 || ((mode == 1 || mode == 3) && x2)), JIRF_EINVAL, "train_gelu: bad arguments");
     const int gx = (int)std::min<long>(2048, (n_img + 255) / 256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Scope sc(intern_label("train_gelu n%ld", n_img), 10.0 * B * (double)n_img, 4.0 * B * (double)n_img * (2 + mode), s);
-    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(gx, B), dim3(256), 0, s, pre, pre_bs ? pre_bs : n_img, x2,
-                       x2_bs ? x2_bs : n_img, y, y_bs ? y_bs : n_img, n_img, mode);
+    Scope sc(intern_label("train_gelu n%ld", n_img), 10.0 * B * (double)n_img, 4.0 * B * (double)n_img * (2 + (mode != 0)), s);
+    const long pbs = pre_bs ? pre_bs : n_img, xbs = x2_bs ? x2_bs : n_img, ybs = y_bs ? y_bs : n_img;
+    auto al = [](const void* p, long bs) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && bs % 4 == 0; };
+    if (n_img % 4 == 0 && al(pre, pbs) && al(y, ybs) && (!x2 || al(x2, xbs))) {
+      const int gx4 = (int)std::min<long>(2048, (n_img / 4 + 255) / 256);
+      hipLaunchKernelGGL(gelu_fwd4_kernel, dim3(gx4, B), dim3(256), 0, s, pre, pbs, x2, xbs, y, ybs, n_img / 4, mode);
+    } else {
+      hipLaunchKernelGGL(gelu_fwd_kernel, dim3(gx, B), dim3(256), 0, s, pre, pbs, x2, xbs, y, ybs, n_img, mode);
+    }
     JIRF_HIP_CHECK(hipGetLastError());
     return JIRF_OK;
   });
@@ -1649,11 +1684,11 @@ int jirf_train_gelu(const float* pre, long pre_bs, const float* x2, long x2_bs, 
 int jirf_train_gelu_bwd(const float* pre, long pre_bs, const float* x2, long x2_bs, const float* dy, long dy_bs,
                         float* dxa, long dxa_bs, float* dxb, long dxb_bs, int B, long n_img, int mode, void* stream) {
   return guarded_t([&] {
-    JIRF_REQUIRE(pre && dy && dxa && B > 0 && n_img > 0 && (mode == 0 || mode == 2 || (mode == 1 && x2 && dxb)), JIRF_EINVAL,
+    JIRF_REQUIRE(pre && dy && dxa && B > 0 && n_img > 0 && (mode == 0 || mode == 2 || ((mode == 1 || mode == 3) && x2 && dxb)), JIRF_EINVAL,
                  "gelu_bwd: bad arguments");
     const int gx = (int)std::min<long>(2048, (n_img + 255) / 256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Scope sc(intern_label("train_gelu_bwd n%ld", n_img), 20.0 * B * (double)n_img, 4.0 * B * (double)n_img * (3 + 2 * (mode == 1)), s);
+    Scope sc(intern_label("train_gelu_bwd n%ld", n_img), 20.0 * B * (double)n_img, 4.0 * B * (double)n_img * (3 + 2 * (mode == 1 || mode == 3)), s);
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(gx, B), dim3(256), 0, s, pre, pre_bs ? pre_bs : n_img, x2,
                        x2_bs ? x2_bs : n_img, dy, dy_bs ? dy_bs : n_img, dxa, dxa_bs ? dxa_bs : n_img, dxb,
                        dxb_bs ? dxb_bs : n_img, n_img, mode);

@@ -392,14 +392,16 @@ class AstTrainStep:
         self.conv(first, self.P(m + ".partial_conv3.weight"), W_FWD, None, None, cat, B, dc, dc, H, W, 3, 1, 1)
         pre1 = self.buf(B, 2 * h, P)
         self.conv(cat, self.P(m + ".linear1.0.weight"), W_FWD, self.P(m + ".linear1.0.bias"), None, pre1, B, Cn, 2 * h, H, W)
-        act1 = self.buf(B, 2 * h, P)
-        self.gelu(pre1, None, act1, B, 2 * h * P, 0)
+        # GELU after linear1 (ast_arch.py:497): materialised only for the half the depthwise 3x3 reads; the gate applies
+        # it to the other half on the fly (mode 3), which halves this pass and the one in the backward
+        act1 = self.buf(B, h, P)
+        self.gelu(pre1, None, act1, B, h * P, 0)
         predw = self.buf(B, h, P)
         check(self.L.jirf_train_dwconv3x3(_vp(act1.ptr), act1.bs, _vp(self.P(m + ".dwconv.0.weight")),
                                           _vp(self.P(m + ".dwconv.0.bias")), _vp(predw.ptr), predw.bs, B, h, H, W, 0,
                                           self._s()))
         gated = self.buf(B, h, P)
-        self.gelu(predw, act1.chan(h, P), gated, B, h * P, 1)
+        self.gelu(predw, pre1.chan(h, P), gated, B, h * P, 3)
         sm = self._branch_scale(bl, "mlp", B)
         if sm is None:
             self.conv(gated, self.P(m + ".linear2.0.weight"), W_FWD, self.P(m + ".linear2.0.bias"), cur, out, B, h, Cn, H, W,
@@ -426,14 +428,15 @@ class AstTrainStep:
         # gate and depthwise 3x3
         dact1 = self.buf(B, 2 * h, P)
         dpredw = self.buf(B, h, P)
-        self.gelu_bwd(sv["predw"], sv["act1"].chan(h, P), dgated, dpredw, dact1.chan(h, P), B, h * P, 1)
+        # (mode 3: the second half's gradient comes out already multiplied by the derivative of linear1's GELU)
+        self.gelu_bwd(sv["predw"], sv["pre1"].chan(h, P), dgated, dpredw, dact1.chan(h, P), B, h * P, 3)
         check(self.L.jirf_train_dwconv3x3_bwd_weight(_vp(sv["act1"].ptr), sv["act1"].bs, _vp(dpredw.ptr), dpredw.bs,
                                                      _vp(self.G(m + ".dwconv.0.weight")), _vp(self.G(m + ".dwconv.0.bias")),
                                                      B, h, H, W, 0, self._s()))
         check(self.L.jirf_train_dwconv3x3(_vp(dpredw.ptr), dpredw.bs, _vp(self.P(m + ".dwconv.0.weight")), None,
                                           _vp(dact1.ptr), dact1.bs, B, h, H, W, 1, self._s()))
-        # GELU after linear1 (in place), linear1
-        self.gelu_bwd(sv["pre1"], None, dact1, dact1, None, B, 2 * h * P, 0)
+        # GELU after linear1 (in place; the first half only, see above), linear1
+        self.gelu_bwd(sv["pre1"], None, dact1, dact1, None, B, h * P, 0)
         self.conv_dw(dact1, sv["cat"], self.G(m + ".linear1.0.weight"), self.G(m + ".linear1.0.bias"), B, 2 * h, Cn, H, W, H, W)
         dcat = self.buf(B, Cn, P)
         self.conv(dact1, self.P(m + ".linear1.0.weight"), W_BWD_DATA, None, None, dcat, B, 2 * h, Cn, H, W)

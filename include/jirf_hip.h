@@ -385,8 +385,10 @@ int jirf_train_layernorm_bwd(const float* x, long x_bs, const float* dy, long dy
                              long add_bs, float* dx, long dx_bs, float* dw, float* db, int B, int C, int P, int kind,
                              int accumulate, void* stream);
 /* Elementwise pieces; one image = n_img contiguous floats.  Forward mode 0: y = gelu(pre) (ast_arch.py:384,456);
- * mode 1: y = gelu(pre) * x2 (the FRFN gate, ast_arch.py:507-510).  Backward mode 0: dxa = dy * gelu'(pre);
- * mode 1: dxa = dy * x2 * gelu'(pre), dxb = dy * gelu(pre); mode 2: LeakyReLU(0.01) with pre = the activation's
+ * mode 1: y = gelu(pre) * x2 (the FRFN gate, ast_arch.py:507-510); mode 3: y = gelu(pre) * gelu(x2) (the same gate on
+ * linear1's raw second half, so that the GELU after linear1 is a pass over the first half only).  Backward mode 0:
+ * dxa = dy * gelu'(pre); mode 1: dxa = dy * x2 * gelu'(pre), dxb = dy * gelu(pre); mode 3: dxa = dy * gelu(x2) *
+ * gelu'(pre), dxb = dy * gelu(pre) * gelu'(x2); mode 2: LeakyReLU(0.01) with pre = the activation's
  * output: dxa = dy * (pre > 0 ? 1 : 0.01). */
 int jirf_train_gelu(const float* pre, long pre_bs, const float* x2, long x2_bs, float* y, long y_bs, int B, long n_img,
                     int mode, void* stream);

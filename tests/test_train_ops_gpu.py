@@ -154,6 +154,16 @@ def test_gelu_and_gate_backward():
     call("jirf_train_gelu", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(yf), 0, B, Cn * P, 1,
          stream())
     assert rel_err(yf.cpu().numpy(), (oc.gelu(a) * b2).detach().numpy()) < 1e-6
+    # the gate on two raw halves (mode 3): y = gelu(a) * gelu(b), gradients with respect to both raw halves
+    bt3 = torch.from_numpy(both).requires_grad_(True)
+    a3, b3 = bt3.chunk(2, dim=1)
+    (oc.gelu(a3) * oc.gelu(b3)).backward(torch.from_numpy(dy))
+    call("jirf_train_gelu_bwd", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(dyd), 0, ptr(dx2),
+         2 * Cn * P, C.c_void_p(dx2.data_ptr() + half), 2 * Cn * P, B, Cn * P, 3, stream())
+    assert rel_err(dx2.cpu().numpy(), bt3.grad.numpy()) < 1e-5
+    call("jirf_train_gelu", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(yf), 0, B, Cn * P, 3,
+         stream())
+    assert rel_err(yf.cpu().numpy(), (oc.gelu(a3) * oc.gelu(b3)).detach().numpy()) < 1e-6
     # y = a + b on slices, and the channel sum
     call("jirf_train_add", ptr(bd), 2 * Cn * P, C.c_void_p(bd.data_ptr() + half), 2 * Cn * P, ptr(yf), 0, B, Cn * P, stream())
     assert rel_err(yf.cpu().numpy(), both[:, :Cn] + both[:, Cn:]) < 1e-6
