@@ -737,8 +737,41 @@ __global__ __launch_bounds__(256) void dwconv_dw_kernel(const float* __restrict_
   const int rows_per = (H + slabs - 1) / slabs;
   const int y_lo = slab * rows_per, y_hi = min(H, y_lo + rows_per);
   const bool vec = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(gp)) & 15) == 0;
-  if (vec) {
-    const int w4 = W >> 2, n4 = (y_hi - y_lo) * w4;
+  // rows of 4 .. 64 float4 that are a power of two: a row's float4s are consecutive lanes of one wave, so the two outer
+  // neighbours of a lane's four pixels are its neighbour lanes' edge pixels (whole-wave DPP shifts, zero at the row
+  // ends) and the position needs no division
+  const int w4 = W >> 2;
+  const bool pow2 = vec && w4 >= 1 && w4 <= 64 && (w4 & (w4 - 1)) == 0;
+  if (pow2) {
+    const int sh = 31 - __builtin_clz(w4), n4 = (y_hi - y_lo) * w4;
+    const int n4r = (n4 + 255) & ~255;                      // every lane of a wave takes part in the shifts
+    for (int i = threadIdx.x; i < n4r; i += 256) {
+      const bool on = i < n4;
+      const int ii = on ? i : 0;
+      const int yy = y_lo + (ii >> sh), x0 = (ii & (w4 - 1)) * 4;
+      float4 g = *reinterpret_cast<const float4*>(gp + (long)yy * W + x0);
+      if (!on) g = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+      acc[9] += (g.x + g.y) + (g.z + g.w);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int sy = yy + ky - 1;
+        const bool rin = sy >= 0 && sy < H;
+        const float4 v0 = *reinterpret_cast<const float4*>(xp + (long)min(max(sy, 0), H - 1) * W + x0);
+        const float4 v = rin ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+        float xl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.w), 0x138, 0xf, 0xf, true));
+        float xr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x130, 0xf, 0xf, true));
+        if (x0 == 0) xl = 0.f;
+        if (x0 + 4 >= W) xr = 0.f;
+        const float xv[6] = {xl, v.x, v.y, v.z, v.w, xr};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ky * 3 + kx] = fmaf(gv[j], xv[j + kx], acc[ky * 3 + kx]);
+      }
+    }
+  } else if (vec) {
+    const int n4 = (y_hi - y_lo) * w4;
     for (int i = threadIdx.x; i < n4; i += 256) {
       const int yy = y_lo + i / w4, x0 = (i % w4) * 4;
       const float4 g = *reinterpret_cast<const float4*>(gp + (long)yy * W + x0);
