@@ -1,7 +1,10 @@
 """Per-launch-shape roofline table from the HIP-event table bench.py writes with --detail.
 Usage: python profiles/make_roofline_table.py profiles/r01_hint_b16_per_shape_hip_events.txt > profiles/r01_roofline_table.md
 Every launch shape is priced against both roofs (fp32 matrix peak 157.3 TFLOP/s, HBM 8 TB/s) with
-its algorithmic FLOPs and bytes; the larger fraction names the roof that bounds it."""
+its algorithmic FLOPs and bytes; the larger fraction names the roof that bounds it.
+`hint_chan_stats` runs half of its FLOPs (the Gram matrix that feeds the channel ranking) on v_mfma_f64_16x16x4, which has
+half the fp32 rate: its matrix roof is 4 / (2 / 157.3 + 2 / 78.65) = 104.9 TFLOP/s; the table prices it against that and
+says so in the bound column."""
 import sys
 
 MFMA, HBM = 157.3, 8000.0
@@ -11,10 +14,11 @@ for line in open(sys.argv[1]):
     if len(f) < 9:
         continue
     ms, launches, tf, gbs, name = float(f[0]), int(f[2]), float(f[4]), float(f[6]), " ".join(f[8:])
-    fm, fh = tf / MFMA, gbs / HBM
+    mixed = name.startswith("hint_chan_stats")
+    fm, fh = tf / (104.9 if mixed else MFMA), gbs / HBM
     matrix = name.startswith("gemm") or "chan_stats" in name
-    bound = "mfma" if (matrix and fm >= fh) else "hbm"
-    rows.append((ms, launches, name, tf, gbs, bound, fm if bound == "mfma" else fh))
+    bound = ("mfma f32+f64" if mixed else "mfma") if (matrix and fm >= fh) else "hbm"
+    rows.append((ms, launches, name, tf, gbs, bound, fm if bound.startswith("mfma") else fh))
 tot = sum(r[0] for r in rows)
 print("| ms/step | share | launches | kernel + shape | TFLOP/s | GB/s | bound | fraction of roof |")
 print("|---:|---:|---:|---|---:|---:|---|---:|")
