@@ -475,13 +475,17 @@ __global__ __launch_bounds__(512) void gdfn_fused_kernel(const GdfnArgs a) {
     __syncthreads();
   };
 
-  for (int yi = ry0 - 1;; yi += 3) {
+  // One loop body: the ring turns by register moves (96 per step) instead of by three unrolled copies of the step with
+  // rotated slot numbers - a third of the code.
+  for (int yi = ry0 - 1; yi <= ry1 + 1; ++yi) {
     step(std::integral_constant<int, 0>{}, std::false_type{}, yi);
-    if (yi + 1 > ry1 + 1) break;
-    step(std::integral_constant<int, 1>{}, std::false_type{}, yi + 1);
-    if (yi + 2 > ry1 + 1) break;
-    step(std::integral_constant<int, 2>{}, std::false_type{}, yi + 2);
-    if (yi + 3 > ry1 + 1) break;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x16 oldest = T[1][t];   // row yi - 2: waves 4-7 still read it (from slot 0) in the next step
+      T[1][t] = T[2][t];
+      T[2][t] = T[0][t];
+      T[0][t] = oldest;
+    }
   }
 }
 
