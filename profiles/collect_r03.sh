@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profiles of the three window-attention networks, the AST optimisation step and the B = 1 call.
+# Profiles of the three window-attention networks, the AST optimisation step and the B = 1 call.
 # Run on the GPU box from the repository root:  bash profiles/collect_r03.sh
 # Per network: a kernel trace, the per-shape HIP-event table of an unprofiled run, and the two traffic passes
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Every GPU step has its own time limit; the first failure ends the run.
