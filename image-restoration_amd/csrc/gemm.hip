@@ -985,208 +985,6 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmArgs a, const
   XS_STAMP(XS_PROBE_SLOTS_LAST);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Split-bf16 form of the activation-stationary GEMM (opt-in, JIRF_GEMM_SPLIT_BF16=1).
-// Every fp32 operand is written as hi + mid + lo with three bf16 values (8 mantissa bits each, so
-// the three pieces carry the full 24-bit significand); a product a * b is then the sum of nine
-// exact bf16 x bf16 products, of which the six largest are accumulated in fp32 on the bf16 matrix
-// cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate):
-//   hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid        (dropped: mid*lo, lo*mid, lo*lo <= 2^-23 |a b|)
-// The accumulation stays fp32, so the result differs from the fp32-MFMA kernel by rounding of the
-// same order as a different summation order.  Layouts: weights [plane][Kp/8][Mpad][8] bf16
-// (pack_wt_split3), the pixel tile in LDS as [plane][pixel][Kp + 8] bf16 so that the eight k of a
-// lane's B fragment are one 16-byte word.
-// ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
-  h = (__bf16)v;
-  float r = v - (float)h;
-  m = (__bf16)r;
-  r -= (float)m;
-  l = (__bf16)r;
-}
-
-constexpr int X3_BN = 64;
-
-template <int LOADER, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_xs3_kernel(const GemmArgs a, const int tiles_n) {
-  constexpr int BN = X3_BN, TNW = 2, PARTS = 256 / BN;
-  extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  const int b = blockIdx.x / tiles_n;
-  const int n0 = (blockIdx.x - b * tiles_n) * BN;
-  const int K = a.K, P = a.P, M = a.M;
-  const int Kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
-  const int LDK = Kp + 8;                                     // bf16 elements per pixel row
-  __bf16* __restrict__ Xb = reinterpret_cast<__bf16*>(x3_smem);      // [3][BN][LDK]
-  float* __restrict__ Xf = reinterpret_cast<float*>(Xb + 3 * BN * LDK);   // [Kp][BN] fp32 staging
-  float* __restrict__ st_mu = Xf + Kp * BN;
-  float* __restrict__ st_rs = st_mu + BN;
-  float* __restrict__ st_part = st_rs + BN;                   // [PARTS][BN]
-  const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
-
-  // ---- load the fp32 tile (rows past K and columns past P are zero) ---------------------------------
-  // (one unpredicated batch per thread, as in gemm_xs_kernel)
-  if constexpr (VEC) {
-    constexpr int LB = 8;
-    const int total = Kp * (BN / 4);
-    const float* __restrict__ xb2 = LOADER == LD_PLAIN && a.k_split > 0 ? a.x2.p + (long)b * a.x2.bs : xb;
-    for (int s0 = tid; s0 < total; s0 += 256 * LB) {
-      float4 v[LB];
-      bool ok[LB];
-#pragma unroll
-      for (int u = 0; u < LB; ++u) {
-        const int s = s0 + u * 256;
-        const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-        const int p = n0 + c4;
-        ok[u] = s < total && k < K && p < P;
-        const int kc = min(k, K - 1);
-        const float* __restrict__ base = (LOADER == LD_PLAIN && kc < a.k_split) ? xb2 : xb;
-        v[u] = *reinterpret_cast<const float4*>(base + (long)kc * P + (p < P ? p : 0));
-      }
-#pragma unroll
-      for (int u = 0; u < LB; ++u) {
-        const int s = s0 + u * 256;
-        if (s < total) {
-          const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-          *reinterpret_cast<float4*>(&Xf[k * BN + c4]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-  } else {
-    for (int s = tid; s < Kp * (BN / 4); s += 256) {
-      const int k = s / (BN / 4), c4 = (s - k * (BN / 4)) * 4;
-      const int p = n0 + c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K && p < P) {
-        const float* __restrict__ src = xb + (long)k * P + p;
-        if constexpr (LOADER == LD_PLAIN) {
-          if (k < a.k_split) src = a.x2.p + (long)b * a.x2.bs + (long)k * P + p;
-        }
-        v.x = src[0];
-        if (p + 1 < P) v.y = src[1];
-        if (p + 2 < P) v.z = src[2];
-        if (p + 3 < P) v.w = src[3];
-      }
-      *reinterpret_cast<float4*>(&Xf[k * BN + c4]) = v;
-    }
-  }
-  __syncthreads();
-  const int col = tid % BN, part = tid / BN;
-  float mu = 0.f, rs = 1.f;
-  if constexpr (LOADER == LD_LN) {
-    float sum = 0.f;
-    for (int k = part; k < K; k += PARTS) sum += Xf[k * BN + col];
-    st_part[part * BN + col] = sum;
-    __syncthreads();
-    sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < PARTS; ++q) sum += st_part[q * BN + col];
-    mu = sum / (float)K;
-    float var = 0.f;
-    for (int k = part; k < K; k += PARTS) {
-      const float d = Xf[k * BN + col] - mu;
-      var = fmaf(d, d, var);
-    }
-    __syncthreads();
-    st_part[part * BN + col] = var;
-    __syncthreads();
-    var = 0.f;
-#pragma unroll
-    for (int q = 0; q < PARTS; ++q) var += st_part[q * BN + col];
-    rs = n0 + col < P ? 1.0f / sqrtf(var / (float)K + 1e-5f) : 0.f;
-    if (!a.ln_center) mu = 0.f;
-  }
-  // ---- normalise, split, transpose into the bf16 planes: thread (pixel col, part) takes the groups
-  //      of eight k with index part, part + PARTS, ...
-  {
-    const bool col_ok = n0 + col < P;
-    for (int g = part; g < Kp / 8; g += PARTS) {
-      bf16x8 hv, mv, lv;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = g * 8 + j;
-        float v = Xf[k * BN + col];
-        if constexpr (LOADER == LD_LN) {
-          const int kc = min(k, K - 1);
-          const float gg = a.lnw ? a.lnw[kc] : 1.f;
-          const float be = a.lnb ? a.lnb[kc] : 0.f;
-          v = (k < K && col_ok) ? (v - mu) * rs * gg + be : 0.f;
-        }
-        __bf16 h, m, l;
-        split3(v, h, m, l);
-        hv[j] = h; mv[j] = m; lv[j] = l;
-      }
-      __bf16* __restrict__ dst = Xb + col * LDK + g * 8;
-      *reinterpret_cast<bf16x8*>(dst) = hv;
-      *reinterpret_cast<bf16x8*>(dst + BN * LDK) = mv;
-      *reinterpret_cast<bf16x8*>(dst + 2 * BN * LDK) = lv;
-    }
-  }
-  __syncthreads();
-
-  // ---- output tiles: wave w takes 32-row tiles w, w + 4, ... over all 64 pixels ---------------------
-  const bf16x8* __restrict__ W3 = reinterpret_cast<const bf16x8*>(a.wt3);
-  const long plane8 = a.wt3_plane / 8;               // 16-byte words per plane
-  const int n_mt = (M + 31) >> 5;
-  const int nks = Kp >> 4;                           // k steps of 16
-  const int epi = a.epi;
-  for (int mt = wave; mt < n_mt; mt += 4) {
-    const int m0 = mt * 32;
-    f32x16 acc[TNW];
-#pragma unroll
-    for (int j = 0; j < TNW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const bf16x8* __restrict__ ap = W3 + (long)half * a.Mpad + min(m0 + l31, a.Mpad - 1);
-    const __bf16* __restrict__ bp = Xb + l31 * LDK + half * 8;
-    bf16x8 ah = ap[0], am = ap[plane8], al = ap[2 * plane8];
-    for (int s = 0; s < nks; ++s) {
-      const int sn = s + 1 < nks ? s + 1 : s;
-      const bf16x8* __restrict__ an = ap + (long)(2 * sn) * a.Mpad;
-      const bf16x8 nh = an[0], nm = an[plane8], nl = an[2 * plane8];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < TNW; ++j) {
-        const __bf16* __restrict__ q = bp + j * 32 * LDK + s * 16;
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(q);
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(q + BN * LDK);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(q + 2 * BN * LDK);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-      }
-      ah = nh; am = nm; al = nl;
-    }
-    float bias_r[16];
-    auto store_all = [&](auto full_tag) {
-      constexpr bool FULL = decltype(full_tag)::value;
-      constexpr int ST = FULL ? ST_FULL : ST_CLAMP;
-      load_bias16<ST>(a, b, m0, half, bias_r);
-#pragma unroll
-      for (int j = 0; j < TNW; ++j) {
-        const int colp = n0 + j * 32 + l31;
-        if (!FULL && n0 + j * 32 >= P) continue;   // wave-uniform
-        if constexpr (LOADER == LD_LN) {
-          store_tile<EP_STORE, ST>(a, b, acc[j], m0, half, colp, bias_r);
-        } else {
-          if (epi == EP_RESID) store_tile<EP_RESID, ST>(a, b, acc[j], m0, half, colp, bias_r);
-          else if (epi == EP_GELU_MUL) store_tile<EP_GELU_MUL, ST>(a, b, acc[j], m0, half, colp, bias_r);
-          else if (epi == EP_GELU) store_tile<EP_GELU, ST>(a, b, acc[j], m0, half, colp, bias_r);
-          else store_tile<EP_STORE, ST>(a, b, acc[j], m0, half, colp, bias_r);
-        }
-      }
-    };
-    if (m0 + 32 <= M && n0 + BN <= P) store_all(std::true_type{});
-    else store_all(std::false_type{});
-  }
-}
-
 #ifdef JIRF_XS_PROBE
 extern "C" int jirf_debug_xs_probe(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xs_probe), sizeof(unsigned long long) * XS_PROBE_WGS * 4 * XS_PROBE_SLOTS);
@@ -1360,66 +1158,6 @@ static bool try_launch_ws(const GemmArgs& a, int loader, bool vec, hipStream_t s
   else JIRF_WS_EPI(3);
 #undef JIRF_WS_EPI
 #undef JIRF_WS_CASE
-  JIRF_HIP_CHECK(hipGetLastError());
-  return true;
-}
-
-bool gemm_split_bf16_enabled() {
-  static const bool on = std::getenv("JIRF_GEMM_SPLIT_BF16") && std::atoi(std::getenv("JIRF_GEMM_SPLIT_BF16")) != 0;
-  return on;
-}
-
-static uint16_t bf16_rne(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);   // inf / nan: truncate
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-static float bf16_to_f32(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float v;
-  std::memcpy(&v, &u, 4);
-  return v;
-}
-
-size_t pack_wt_split3(const float* w, int M, int K, int Mpad, std::vector<uint16_t>& out) {
-  const int kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
-  const size_t plane = (size_t)kp * Mpad;
-  out.assign(3 * plane, 0);
-  for (int o = 0; o < M; ++o)
-    for (int k = 0; k < K; ++k) {
-      const float v = w[(size_t)o * K + k];
-      const uint16_t h = bf16_rne(v);
-      const float r1 = v - bf16_to_f32(h);
-      const uint16_t m = bf16_rne(r1);
-      const uint16_t l = bf16_rne(r1 - bf16_to_f32(m));
-      const size_t at = ((size_t)(k / 8) * Mpad + o) * 8 + (k % 8);
-      out[at] = h; out[plane + at] = m; out[2 * plane + at] = l;
-    }
-  return plane;
-}
-
-static bool try_launch_xs3(const GemmArgs& a, int loader, bool vec, hipStream_t s) {
-  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || a.K > 128) return false;
-  if (loader != LD_PLAIN && loader != LD_LN) return false;
-  if (loader == LD_PLAIN && (a.epi == EP_SHUFFLE || a.epi == EP_UNSHUFFLE || a.epi == EP_LEAKY)) return false;
-  const int tiles_n = (a.P + X3_BN - 1) / X3_BN;
-  const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
-  const size_t smem = (size_t)3 * X3_BN * (Kp + 8) * 2 + ((size_t)Kp * X3_BN + 2 * X3_BN + 256) * 4;
-  const dim3 grid((unsigned)(tiles_n * a.B)), block(256);
-#define JIRF_X3_CASE(LD, V)                                                                            \
-  do {                                                                                                 \
-    static DynLdsOnce once;                                        \
-    allow_dynamic_lds(once, reinterpret_cast<const void*>(gemm_xs3_kernel<LD, V>), 96 * 1024); \
-    hipLaunchKernelGGL((gemm_xs3_kernel<LD, V>), grid, block, smem, s, a, tiles_n);                    \
-  } while (0)
-  if (loader == LD_LN) {
-    if (vec) JIRF_X3_CASE(LD_LN, true); else JIRF_X3_CASE(LD_LN, false);
-  } else {
-    if (vec) JIRF_X3_CASE(LD_PLAIN, true); else JIRF_X3_CASE(LD_PLAIN, false);
-  }
-#undef JIRF_X3_CASE
   JIRF_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -1621,7 +1359,7 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   static const int forced = std::getenv("JIRF_GEMM_TILE") ? std::atoi(std::getenv("JIRF_GEMM_TILE")) : -1;
   const bool xs = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
                   (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
-  if ((xs || (gemm_split_bf16_enabled() && a.K <= 128 && loader == LD_PLAIN)) && try_launch_xs3(a, loader, vec, s)) return;
+  if (xs && gemm_split_bf16_enabled() && try_launch_gemm_b3(a, loader, s)) return;
   if (!xs && try_launch_ws(a, loader, vec, s)) return;
   if (xs) {
     // 128-pixel tiles need K <= 128 (LDS) and enough of them: an underfilled grid does better with 64-pixel

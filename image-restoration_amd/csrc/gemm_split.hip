@@ -1,0 +1,270 @@
+// Split-bf16 GEMM with the pixel operand held in registers (gfx950), for short reductions (K <= 96).
+//
+// Every fp32 operand is written exactly as hi + mid + lo with three bf16 values (8 significand bits each,
+// 24 together); a product a * b is then the sum of nine exact bf16 x bf16 products, of which the six largest
+// are accumulated in fp32 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate):
+//   hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid      (dropped: mid*lo, lo*mid, lo*lo <= 2^-23 |a b|)
+// so the result differs from an fp32 fma chain by rounding of the same order as a different summation order.
+//
+// Layout.  A wave owns 32 pixels for its whole life.  Lane (pixel l31, half h) loads the channels
+// 16 s + 8 h + i (i < 8) of its pixel with one dword load each — 128-byte row segments, the row advance in
+// the scalar offset — so all channels of a pixel sit in lanes l and l + 32: LayerNorm is two register passes
+// and one lane swap, and the normalised values are split and packed straight into MFMA B fragments (eight
+// consecutive k per lane).  The activation tile never passes through LDS.  The weights stream through LDS
+// instead: one chunk = the three bf16 planes of a 32-row output tile, copied by the whole workgroup a tile
+// ahead (global memory -> LDS with no register in between, one barrier per tile) and read by every wave as A
+// fragments, 16 bytes per lane, conflict-free.  Each output tile is 36 MFMAs at K = 96 and 16 dword stores
+// per lane.  125 registers at K = 96: four waves per SIMD, four workgroups (of 128 pixels) per CU.
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "common.h"
+
+namespace jirf {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// t[l] + t[l ^ 32]: v_permlane32_swap exchanges the upper half of its first operand with the lower half of
+// its second; fed two copies of t, each lane then holds its own value in one and its partner's in the other.
+// (Written as assembly: through the builtin with the same value twice, the compiler takes the two results
+// for equal and adds one of them to itself.)
+__device__ __forceinline__ float swap32_sum(float t) {
+  float u = t;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(u));
+  return t + u;
+}
+
+// eight fp32 values -> the three bf16 planes of one B fragment
+__device__ __forceinline__ void split8(const float* v, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hi = (__bf16)v[i];
+    const float r1 = v[i] - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    const float r2 = r1 - (float)mi;
+    h[i] = hi;
+    m[i] = mi;
+    l[i] = (__bf16)r2;
+  }
+}
+
+// One 1 KiB piece of a weight chunk, global memory -> LDS with no register in between: lane l's 16 bytes land at
+// lds_dst + 16 l.  Written as assembly so that the compiler does not count it: it would otherwise wait for the
+// copy before the next LDS read of the OTHER buffer.  The issuing wave waits (vmcnt) before the barrier that
+// hands the buffer to the readers.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+constexpr int B3_WAVES = 4;
+constexpr int B3_BN = 32 * B3_WAVES;   // pixels per workgroup
+
+template <int NS, bool LN>
+__global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArgs a, const int tiles_n) {
+  constexpr int K = NS * 16;
+  constexpr int NG = NS * 2;                    // groups of eight k
+  constexpr int CH = 3 * NG * 32;               // 16-byte slots of one weight chunk (plane, k group, row)
+  constexpr int PIECES = CH / 64;               // 1 KiB pieces of a chunk
+  constexpr int PW = (PIECES + B3_WAVES - 1) / B3_WAVES;   // pieces a wave copies
+  constexpr int NT = 64 * B3_WAVES;
+  __shared__ __attribute__((aligned(16))) u32x4 Abuf[2][CH];
+  extern __shared__ __attribute__((aligned(16))) float b3_bias[];   // [ceil32(M)]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / tiles_n;
+  const int n0 = (blockIdx.x - b * tiles_n) * B3_BN;
+  const int P = a.P, M = a.M;
+  const int n_mt = (M + 31) >> 5;
+
+  // ---- weight chunks: [plane][k group][Mpad] 16-byte words in global memory; wave w copies pieces w, w + 4, ...
+  const u32x4* __restrict__ W3 = reinterpret_cast<const u32x4*>(a.wt3);
+  const int plane16 = (int)(a.wt3_plane / 8);
+  const u32x4* w_src[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int q = min((wave + i * B3_WAVES) * 64 + lane, CH - 1);
+    const int pl = q / (NG * 32), g = (q >> 5) % NG, m = q & 31;
+    w_src[i] = W3 + pl * plane16 + g * a.Mpad + m;
+  }
+  const unsigned abuf0 = (unsigned)(uintptr_t)&Abuf[0][0];   // LDS byte address
+  auto copy_chunk = [&](int mt, int buf) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i)
+      if (PIECES % B3_WAVES == 0 || wave + i * B3_WAVES < PIECES)   // wave-uniform
+        dma16(w_src[i] + mt * 32, abuf0 + (unsigned)(buf * CH + (wave + i * B3_WAVES) * 64) * 16u);
+  };
+  copy_chunk(0, 0);
+
+  // ---- the wave's 32 pixels: load, normalise, split ---------------------------------------------------
+  const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)min((long)K * P * 4, 0x7fffffffL), 0x00020000);
+  const int pix = n0 + wave * 32 + l31;
+  const int x_voff = (8 * half * P + min(pix, P - 1)) * 4;
+  float raw[NS][8];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      raw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_voff, (16 * s + i) * P * 4, 0));
+
+  {   // the output bias waits in LDS (rows past M as zeros)
+    const float* __restrict__ bsrc = a.bias ? a.bias + (long)b * a.bias_bs : nullptr;
+    for (int m = tid; m < n_mt * 32; m += NT) b3_bias[m] = bsrc && m < M ? bsrc[m] : 0.f;
+  }
+
+  if constexpr (LN) {
+    // mean and population variance in two passes, as the reference's mean / var(unbiased=False)
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += raw[s][i];
+    sum = swap32_sum(sum);
+    const float inv_k = 1.0f / (float)K;
+    const float mu = sum * inv_k;
+    float q = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = raw[s][i] - mu;
+        q = fmaf(d, d, q);
+      }
+    q = swap32_sum(q);
+    const float rs = __builtin_amdgcn_rsqf(q * inv_k + 1e-5f);
+    const float mc = a.ln_center ? mu : 0.f;   // BiasFree does not centre
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) raw[s][i] = (raw[s][i] - mc) * rs;
+  }
+  bf16x8 Bh[NS], Bm[NS], Bl[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) split8(raw[s], Bh[s], Bm[s], Bl[s]);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk 0 is in LDS
+  __syncthreads();
+
+  // ---- output tiles ------------------------------------------------------------------------------------
+  float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
+  const __amdgpu_buffer_rsrc_t y_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
+  const int OOB = 0x7fffffff;
+  const int y_voff = pix < P ? (4 * half * P + pix) * 4 : OOB;
+
+  for (int mt = 0; mt < n_mt; ++mt) {
+    const int buf = mt & 1;
+    if (mt + 1 < n_mt) copy_chunk(mt + 1, buf ^ 1);
+    const int m0 = mt * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b3_bias[m0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    const bf16x8* __restrict__ Ab = reinterpret_cast<const bf16x8*>(&Abuf[buf][half * 32 + l31]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bf16x8 ah = Ab[(0 * NG + 2 * s) * 32];
+      const bf16x8 am = Ab[(1 * NG + 2 * s) * 32];
+      const bf16x8 al = Ab[(2 * NG + 2 * s) * 32];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, Bm[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, Bh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, Bl[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, Bh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, Bm[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, Bh[s], acc, 0, 0, 0);
+    }
+    // the next chunk has landed (and, the counter being one, the previous tile's stores are done)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (m0 + 32 <= M) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), y_rsrc, y_voff, (m0 + (r & 3) + 8 * (r >> 2)) * P * 4, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2);
+        const int vo = row + 4 * half < M ? y_voff : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), y_rsrc, vo, min(row, M - 1) * P * 4, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+bool gemm_split_bf16_enabled() {
+  static const bool on = std::getenv("JIRF_GEMM_SPLIT_BF16") && std::atoi(std::getenv("JIRF_GEMM_SPLIT_BF16")) != 0;
+  return on;
+}
+bool gemm_split_bf16_covers(int K) { return K % 16 == 0 && K <= 96 && K != 80; }
+
+static uint16_t bf16_rne(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);   // inf / nan: truncate
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float v;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+
+size_t pack_wt_split3(const float* w, int M, int K, int Mpad, std::vector<uint16_t>& out) {
+  const int kp = (K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  const size_t plane = (size_t)kp * Mpad;
+  out.assign(3 * plane, 0);
+  for (int o = 0; o < M; ++o)
+    for (int k = 0; k < K; ++k) {
+      const float v = w[(size_t)o * K + k];
+      const uint16_t h = bf16_rne(v);
+      const float r1 = v - bf16_to_f32(h);
+      const uint16_t m = bf16_rne(r1);
+      const uint16_t l = bf16_rne(r1 - bf16_to_f32(m));
+      const size_t at = ((size_t)(k / 8) * Mpad + o) * 8 + (k % 8);
+      out[at] = h; out[plane + at] = m; out[2 * plane + at] = l;
+    }
+  return plane;
+}
+
+// LayerNorm or plain 1x1 GEMM with a plain store; false when the shape is not one this kernel is built for.
+bool try_launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
+  if (!a.wt3 || a.wt_bs != 0 || a.epi != EP_STORE || a.k_split > 0) return false;
+  if (loader != LD_LN && loader != LD_PLAIN) return false;
+  if (!gemm_split_bf16_covers(a.K)) return false;
+  if (loader == LD_LN && a.lnw) return false;   // the affine part must be folded into the weights
+  if ((long)a.M * a.P * 4 > 0x7fffffffL || (long)a.K * a.P * 4 > 0x7fffffffL) return false;
+  const int tiles_n = (a.P + B3_BN - 1) / B3_BN;
+  const size_t smem = (size_t)((a.M + 31) / 32 * 32) * sizeof(float);
+  const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * B3_WAVES);
+#define JIRF_B3_CASE(NS)                                                                             \
+  case NS:                                                                                           \
+    if (loader == LD_LN) hipLaunchKernelGGL((gemm_b3_kernel<NS, true>), grid, block, smem, s, a, tiles_n);   \
+    else hipLaunchKernelGGL((gemm_b3_kernel<NS, false>), grid, block, smem, s, a, tiles_n);           \
+    break
+  switch (a.K / 16) {
+    JIRF_B3_CASE(2);
+    JIRF_B3_CASE(3);
+    JIRF_B3_CASE(4);
+    JIRF_B3_CASE(6);
+    default: return false;
+  }
+#undef JIRF_B3_CASE
+  JIRF_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+}  // namespace jirf

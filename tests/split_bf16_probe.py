@@ -13,7 +13,10 @@ from tests.gpu_util import call, dev, hptr, ptr, stream
 def main():
     rng = np.random.default_rng(11)
     out = {}
-    for (B, C, Cout, P) in [(2, 48, 254, 4096), (1, 96, 510, 4100), (1, 127, 48, 1000), (1, 128, 96, 777)]:
+    # reduction lengths the split kernel covers (32, 48, 64, 96; ragged pixel counts and output-row tails), and one it
+    # does not (127: both runs then use the same fp32 kernel)
+    for (B, C, Cout, P) in [(2, 48, 254, 4096), (1, 96, 510, 4100), (2, 96, 288, 777), (1, 64, 170, 1000), (1, 32, 96, 333),
+                            (1, 127, 48, 1000)]:
         x = rng.standard_normal((B, C, P)).astype(np.float32) * 2 + 0.5
         w = (rng.standard_normal((Cout, C)) * C ** -0.5).astype(np.float32)
         res = rng.standard_normal((B, Cout, P)).astype(np.float32)
@@ -22,6 +25,8 @@ def main():
         call("jirf_op_conv1x1", ptr(xd), hptr(w), None, ptr(rd), ptr(y), B, C, Cout, P, stream())
         ref = np.einsum("oi,bip->bop", w.astype(np.float64), x.astype(np.float64)) + res
         out[f"conv1x1_{C}_{Cout}_{P}"] = float(np.abs(y.cpu().numpy() - ref).max())
+        call("jirf_op_conv1x1", ptr(xd), hptr(w), None, None, ptr(y), B, C, Cout, P, stream())
+        out[f"conv1x1_plain_{C}_{Cout}_{P}"] = float(np.abs(y.cpu().numpy() - (ref - res)).max())
         lw = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
         lb = (0.1 * rng.standard_normal(C)).astype(np.float32)
         x64 = x.astype(np.float64)

@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _probe(split):
     path = os.pathsep.join([ROOT, os.path.join(ROOT, "image-restoration_amd"), os.environ.get("PYTHONPATH", "")])
-    env = dict(os.environ, JIRF_GEMM_SPLIT_BF16="1" if split else "0", PYTHONPATH=path)
+    # JIRF_OP_LN_FOLD: the LayerNorm weight and bias folded into the GEMM weights, the form the networks run (the
+    # split kernel only normalises)
+    env = dict(os.environ, JIRF_GEMM_SPLIT_BF16="1" if split else "0", JIRF_OP_LN_FOLD="1", PYTHONPATH=path)
     r = subprocess.run([sys.executable, "-m", "tests.split_bf16_probe"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=110)
     assert r.returncode == 0, r.stderr[-2000:]
