@@ -29,6 +29,8 @@ import numpy as np
 import torch
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f32), dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X bf16 matrix peak (v_mfma_f32_32x32x16_bf16), dense
+SPLIT_TERMS = 6                # bf16 partial products the split GEMM kernels issue per fp32 product
 HBM_PEAK_GBS = 8000.0
 
 
@@ -100,6 +102,20 @@ def _dominant(detail):
     name, a = max(detail.items(), key=lambda kv: kv[1]["ms"])
     family = name.split(" ")[0]
     per_launch_s = a["ms"] / 1e3 / a["launches"]
+    if family.endswith("_bf16x3"):
+        # split GEMM: the matrix pipe executes SPLIT_TERMS bf16 products per algorithmic fp32 product; the bound is
+        # whichever of the two floors (HBM bytes at 8 TB/s, issued bf16 flops at the dense bf16 peak) is the longer
+        issued = SPLIT_TERMS * a["flops"] / a["launches"]
+        nbytes = a["bytes"] / a["launches"]
+        if nbytes / (HBM_PEAK_GBS * 1e9) >= issued / (MFMA_BF16_PEAK_TFLOPS * 1e12):
+            ach = nbytes / per_launch_s / 1e9
+            return name, {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                          "issued_bf16_tflops": round(issued / per_launch_s / 1e12, 1)}
+        ach = issued / per_launch_s / 1e12
+        return name, {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                      "note": f"issued bf16 flops = {SPLIT_TERMS} x the algorithmic fp32 flops"}
     if family.startswith("gemm") or family == "hint_chan_stats" or family.startswith("win_attn") or \
             family in ("train_dw", "train_win_attn_bwd"):
         ach = a["flops"] / a["launches"] / per_launch_s / 1e12
@@ -504,6 +520,58 @@ def main():
                                    f"overlap {args.overlap_size} and mean-blended" if args.crop_size else "")),
                    "batch_per_gpu": B, "height": Hh, "width": Ww, "sharding": "images round-robin over ranks, no collective"},
     }
+    import jirf_hip as _jh
+    split_on = bool(_jh.lib().jirf_set_gemm_split_bf16(1))
+    _jh.lib().jirf_set_gemm_split_bf16(int(split_on))
+    out["config"]["gemm_arithmetic"] = (
+        "fp32 in, fp32 out, fp32 accumulation; matrix-bound GEMMs with shared weights form each fp32 product from three "
+        "exact bf16 terms per operand (six of the nine partial products, each exact) on v_mfma_f32_32x32x16_bf16 - error "
+        "against float64 at or below the fp32 matrix instruction's (tests/test_split_bf16_gpu.py); the other contractions "
+        "use v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64" if split_on else
+        "v_mfma_f32_32x32x2_f32 (fp32 matrix instruction) for every fp32 contraction; v_mfma_f64_16x16x4_f64 for the Gram matrix")
+    if rank == 0 and world == 1 and split_on and not args.host_io and not script_path:
+        # the same steps with every GEMM on the fp32 matrix instruction (a second network, packed under that setting)
+        _jh.lib().jirf_set_gemm_split_bf16(0)
+        try:
+            net32 = define_network(dict(cfg, type=args.arch))
+            net32.load_state_dict(sd)
+            net32.cuda(local_rank).eval()
+            net32.batch_mode = "per_image"
+
+            def step32():
+                if args.arch == "HINT":
+                    net32.qv_cache = None
+                return net32(x)
+            for _ in range(args.warmup):
+                step32()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                y32 = step32()
+            torch.cuda.synchronize()
+            ms32 = (time.perf_counter() - t0) / args.steps * 1e3
+            rec32 = {"value": round(mp_per_step / (ms32 / 1e3), 3), "unit": "MP/s", "ms_per_step": round(ms32, 3),
+                     "ms_per_image": round(ms32 / B, 4), "steps": args.steps, "warmup": args.warmup,
+                     "what": "the same batch and step count with JIRF_GEMM_SPLIT_BF16=0: every GEMM on v_mfma_f32_32x32x2_f32"}
+            if args.arch == "HINT":
+                # HINT ranks channels by an argsort of correlations (hint_arch.py:241-296): rounding-level differences
+                # reorder near-ties, and the output is discontinuous in the order.  So the two arithmetics are compared
+                # once as they run and once with the fp32 network on the channel orders the headline network chose.
+                p_split, p_32 = net.last_perms(groups=B), net32.last_perms(groups=B)
+                rec32["free_running"] = {
+                    "max_abs_diff_of_outputs": float((y32 - y).abs().max()),
+                    "images_x_attention_blocks_with_a_different_channel_order":
+                        int(sum(int((a_ != b_).any(axis=1).sum()) for a_, b_ in zip(p_split, p_32))),
+                    "of": int(sum(a_.shape[0] for a_ in p_split))}
+                net32.force_perms(p_split)
+                rec32["same_channel_orders"] = {"max_abs_diff_of_outputs": float((step32() - y).abs().max())}
+                net32.force_perms(None)
+            else:
+                rec32["max_abs_diff_of_outputs"] = float((y32 - y).abs().max())
+            out["fp32_mfma_gemm"] = rec32
+            del net32, y32
+        finally:
+            _jh.lib().jirf_set_gemm_split_bf16(1)
     if flops_img and not script_path:
         out["model_tflops_per_s"] = round(world * B * flops_img / (ms_per_step / 1e3) / 1e12, 2)
         out["frac_of_f32_mfma_peak"] = round(B * flops_img / (ms_per_step / 1e3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)

@@ -128,8 +128,9 @@ bool gemm_split_bf16_covers(int K);
 // [plane][Kp / 8][Mpad][8]: the 8 consecutive k of one MFMA operand are one 16-byte word per row.
 // Returns elements per plane.
 size_t pack_wt_split3(const float* w, int M, int K, int Mpad, std::vector<uint16_t>& out);
-// split-bf16 GEMM with the pixel operand in registers (gemm_split.hip); false: shape not covered, nothing launched
-bool try_launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s);
+// split-bf16 GEMM with the pixel operand in registers (gemm_split.hip): whether it serves this launch, and the launch
+bool gemm_b3_covers(const GemmArgs& a, int loader);
+void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s);
 // host-side packers (return Kpad; out is resized to Kpad * Mpad)
 int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad);
 int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad);

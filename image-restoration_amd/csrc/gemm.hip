@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "split_bf16.h"
 
 namespace jirf {
 
@@ -479,6 +480,163 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_kernel(const G
     else if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
     else if (epi == EP_LEAKY) run_epilogue(std::integral_constant<int, EP_LEAKY>{});
     else run_epilogue(std::integral_constant<int, EP_STORE>{});
+  } else {
+    if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
+    else if (epi == EP_GELU_MUL) run_epilogue(std::integral_constant<int, EP_GELU_MUL>{});
+    else if (epi == EP_GELU) run_epilogue(std::integral_constant<int, EP_GELU>{});
+    else if (epi == EP_SHUFFLE) run_epilogue(std::integral_constant<int, EP_SHUFFLE>{});
+    else run_epilogue(std::integral_constant<int, EP_STORE>{});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 form of the K-loop kernel (opt-in, see gemm_split.hip for the arithmetic): 128 x 128 tiles,
+// four waves of 64 x 64, K stepped by 16.  The weights come pre-split from global memory ([plane][k / 8]
+// [Mpad] 16-byte words); an activation element is split once per workgroup on its way to LDS: thread
+// (k group g, pixel px) loads the eight channels 16 kt + 8 g .. + 7 of its pixel with one dword load each
+// (128-byte row segments), normalises them if LayerNorm rides on the load, and writes the three bf16 planes
+// as one 16-byte word each.  Both LDS images are [plane][k group][row or pixel] 16-byte words, so a wave's
+// fragment read is 1 KiB contiguous: conflict-free.  24 MFMAs per wave between barriers.
+// ------------------------------------------------------------------------------------------------
+constexpr int T3_B = 128;
+
+template <int LOADER>
+__global__ __launch_bounds__(256, 3) void gemm_t3_kernel(const GemmArgs a, const int tiles_m, const int tiles_n) {
+  __shared__ __attribute__((aligned(16))) u32x4 As[2][3 * 2 * T3_B];
+  __shared__ __attribute__((aligned(16))) u32x4 Bs[2][3 * 2 * T3_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int g = wave >> 1;                       // the k group this thread stages (wave-uniform)
+  const int srow = tid & (T3_B - 1);             // ... and its row (weights) / pixel (activations)
+  const int per_img = tiles_m * tiles_n;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = id / per_img;
+  id -= b * per_img;
+  const int tile_n = id / tiles_m;
+  const int tile_m = id - tile_n * tiles_m;
+  const int m0 = tile_m * T3_B, n0 = tile_n * T3_B;
+  const int K = a.K, P = a.P;
+  const int nk = (K + 15) >> 4;
+
+  const u32x4* __restrict__ W3 = reinterpret_cast<const u32x4*>(a.wt3) + min(m0 + srow, a.Mpad - 1);
+  const int plane16 = (int)(a.wt3_plane / 8);
+  const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)min((long)K * P * 4, 0x7fffffffL), 0x00020000);
+  const float* __restrict__ xb2 = LOADER == LD_PLAIN && a.k_split > 0 ? a.x2.p + (long)b * a.x2.bs : xb;
+  const __amdgpu_buffer_rsrc_t x2_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb2), 0, (int)min((long)K * P * 4, 0x7fffffffL), 0x00020000);
+  const int pcl = min(n0 + srow, P - 1);         // columns past the image load a valid pixel and are never stored
+  const int x_voff = pcl * 4;
+  float ln_mu = 0.f, ln_rs = 1.f;
+  if constexpr (LOADER == LD_LN) {
+    ln_mu = a.ln_center ? a.mu[(long)b * P + pcl] : 0.f;
+    ln_rs = a.rstd[(long)b * P + pcl];
+  }
+
+  u32x4 wa[3];
+  float raw[8];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wa[i] = W3[i * plane16 + (2 * kt + g) * a.Mpad];
+    const int k0 = 16 * kt + 8 * g;              // wave-uniform: the row advance is a scalar offset
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 + i;
+      float v = 0.f;
+      if (k < K) {                               // rows past K stay zero (their weights are zero padding)
+        if (LOADER == LD_PLAIN && k < a.k_split) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x2_rsrc, x_voff, k * P * 4, 0));
+        else v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_voff, k * P * 4, 0));
+      }
+      raw[i] = v;
+    }
+  };
+  auto stage = [&](int kt, int buf) {
+    if constexpr (LOADER == LD_LN) {
+      const int k0 = 16 * kt + 8 * g;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = k0 + i;
+        float v = (raw[i] - ln_mu) * ln_rs;
+        if (a.lnw) v = v * a.lnw[min(k, K - 1)] + (a.lnb ? a.lnb[min(k, K - 1)] : 0.f);
+        raw[i] = k < K ? v : 0.f;
+      }
+    }
+    bf16x8 h, m, l;
+    split8(raw, h, m, l);
+    Bs[buf][0 * 2 * T3_B + tid] = __builtin_bit_cast(u32x4, h);
+    Bs[buf][1 * 2 * T3_B + tid] = __builtin_bit_cast(u32x4, m);
+    Bs[buf][2 * 2 * T3_B + tid] = __builtin_bit_cast(u32x4, l);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) As[buf][i * 2 * T3_B + tid] = wa[i];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch(0);
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) fetch(kt + 1);
+    const bf16x8* __restrict__ Ab = reinterpret_cast<const bf16x8*>(&As[buf][half * T3_B + wm * 64 + l31]);
+    const bf16x8* __restrict__ Bb = reinterpret_cast<const bf16x8*>(&Bs[buf][half * T3_B + wn * 64 + l31]);
+    bf16x8 af[3][2], bfr[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[pl][i] = Ab[pl * 2 * T3_B + i * 32];
+        bfr[pl][i] = Bb[pl * 2 * T3_B + i * 32];
+      }
+    // the six terms of a product, smallest first; consecutive MFMAs go to different accumulators
+    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bfr[TB[t]][j], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    __syncthreads();
+  }
+
+  auto run_epilogue = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = m0 + wm * 64 + i * 32;
+      if (rbase >= a.M) continue;   // wave-uniform: a padding tile
+      float bias_r[16];
+      if (rbase + 32 <= a.M) {
+        load_bias16<ST_FULL>(a, b, rbase, half, bias_r);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cbase = n0 + wn * 64 + j * 32;
+          if (cbase + 32 <= P) store_tile<EPI, ST_FULL>(a, b, acc[i][j], rbase, half, cbase + l31, bias_r);
+          else if (cbase < P) store_tile<EPI, ST_PRED>(a, b, acc[i][j], rbase, half, cbase + l31, bias_r);
+        }
+      } else {
+        load_bias16<ST_PRED>(a, b, rbase, half, bias_r);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cbase = n0 + wn * 64 + j * 32;
+          if (cbase < P) store_tile<EPI, ST_PRED>(a, b, acc[i][j], rbase, half, cbase + l31, bias_r);
+        }
+      }
+    }
+  };
+  const int epi = a.epi;
+  if constexpr (LOADER == LD_LN) {
+    run_epilogue(std::integral_constant<int, EP_STORE>{});
   } else {
     if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
     else if (epi == EP_GELU_MUL) run_epilogue(std::integral_constant<int, EP_GELU_MUL>{});
@@ -1162,11 +1320,30 @@ static bool try_launch_ws(const GemmArgs& a, int loader, bool vec, hipStream_t s
   return true;
 }
 
+// the split-bf16 K-loop kernel: long reductions on grids that fill the chip, shared weights
+static bool t3_covers(const GemmArgs& a, int loader) {
+  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0) return false;
+  if (loader != LD_PLAIN && loader != LD_LN) return false;
+  if (loader == LD_LN && (!a.mu || !a.rstd)) return false;
+  if (a.M < 128 || a.K <= 96) return false;
+  if ((long)a.K * a.P * 4 > 0x7fffffffL) return false;
+  return (long)((a.M + T3_B - 1) / T3_B) * ((a.P + T3_B - 1) / T3_B) * a.B >= 512;
+}
+static void launch_t3(const GemmArgs& a, int loader, hipStream_t s) {
+  const int tiles_m = (a.M + T3_B - 1) / T3_B, tiles_n = (a.P + T3_B - 1) / T3_B;
+  const long blocks = (long)tiles_m * tiles_n * a.B;
+  const dim3 grid((unsigned)blocks), block(256);
+  if (loader == LD_LN) hipLaunchKernelGGL((gemm_t3_kernel<LD_LN>), grid, block, 0, s, a, tiles_m, tiles_n);
+  else hipLaunchKernelGGL((gemm_t3_kernel<LD_PLAIN>), grid, block, 0, s, a, tiles_m, tiles_n);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
 static bool xs_enabled() {
   static const bool on = !std::getenv("JIRF_GEMM_NO_XS") && !std::getenv("JIRF_GEMM_TILE");
   return on;
 }
-bool gemm_ln_inline(int K) { return K <= 256 && xs_enabled(); }
+// (with the split-bf16 kernels on, reductions past 96 go to the K-loop form, which reads the statistics)
+bool gemm_ln_inline(int K) { return K <= 256 && xs_enabled() && !(gemm_split_bf16_enabled() && K > 96); }
 
 template <int BN, int TNW>
 static void launch_xs(const GemmArgs& a_in, int loader, bool vec, hipStream_t s) {
@@ -1342,7 +1519,12 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   double bytes = 4.0 * a.B * (double)a.P * (kin + a.M) + 4.0 * a.K * (double)a.M * (a.wt_bs ? a.B : 1);
   if (a.epi == EP_RESID || a.epi == EP_GELU_MUL) bytes += 4.0 * a.B * (double)a.P * a.M;
   if (a.epi == EP_AV_INTRA) bytes += 4.0 * a.B * (double)a.P * a.M * 3;
-  Scope sc(intern_label("%s M%d K%d P%d", name, a.M, a.K, a.P), flops, bytes, s);
+  // which kernel serves the launch is part of the label: the split-bf16 forms are priced against another roof
+  static const bool tile_forced_early = std::getenv("JIRF_GEMM_TILE") != nullptr;
+  const bool xs_shape = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
+                        (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
+  const int split_kind = tile_forced_early ? 0 : (xs_shape && gemm_b3_covers(a, loader)) ? 1 : t3_covers(a, loader) ? 2 : 0;
+  Scope sc(intern_label("%s%s M%d K%d P%d", name, split_kind ? "_bf16x3" : "", a.M, a.K, a.P), flops, bytes, s);
 
   // the RGB output convolutions: a handful of output rows would idle the matrix cores
   static const bool tile_forced = std::getenv("JIRF_GEMM_TILE") != nullptr;
@@ -1359,7 +1541,8 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   static const int forced = std::getenv("JIRF_GEMM_TILE") ? std::atoi(std::getenv("JIRF_GEMM_TILE")) : -1;
   const bool xs = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
                   (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
-  if (xs && gemm_split_bf16_enabled() && try_launch_gemm_b3(a, loader, s)) return;
+  if (split_kind == 1) return launch_gemm_b3(a, loader, s);
+  if (split_kind == 2) return launch_t3(a, loader, s);
   if (!xs && try_launch_ws(a, loader, vec, s)) return;
   if (xs) {
     // 128-pixel tiles need K <= 128 (LDS) and enough of them: an underfilled grid does better with 64-pixel

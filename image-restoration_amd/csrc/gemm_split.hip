@@ -15,20 +15,19 @@
 // ahead (global memory -> LDS with no register in between, one barrier per tile) and read by every wave as A
 // fragments, 16 bytes per lane, conflict-free.  Each output tile is 36 MFMAs at K = 96 and 16 dword stores
 // per lane.  125 registers at K = 96: four waves per SIMD, four workgroups (of 128 pixels) per CU.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
 #include "common.h"
+#include "split_bf16.h"
 
 namespace jirf {
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 // t[l] + t[l ^ 32]: v_permlane32_swap exchanges the upper half of its first operand with the lower half of
 // its second; fed two copies of t, each lane then holds its own value in one and its partner's in the other.
 // (Written as assembly: through the builtin with the same value twice, the compiler takes the two results
@@ -37,20 +36,6 @@ __device__ __forceinline__ float swap32_sum(float t) {
   float u = t;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t), "+v"(u));
   return t + u;
-}
-
-// eight fp32 values -> the three bf16 planes of one B fragment
-__device__ __forceinline__ void split8(const float* v, bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 hi = (__bf16)v[i];
-    const float r1 = v[i] - (float)hi;
-    const __bf16 mi = (__bf16)r1;
-    const float r2 = r1 - (float)mi;
-    h[i] = hi;
-    m[i] = mi;
-    l[i] = (__bf16)r2;
-  }
 }
 
 // One 1 KiB piece of a weight chunk, global memory -> LDS with no register in between: lane l's 16 bytes land at
@@ -203,11 +188,13 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
 
 }  // namespace
 
-bool gemm_split_bf16_enabled() {
-  static const bool on = std::getenv("JIRF_GEMM_SPLIT_BF16") && std::atoi(std::getenv("JIRF_GEMM_SPLIT_BF16")) != 0;
+static std::atomic<int>& split_flag() {
+  static std::atomic<int> on{std::getenv("JIRF_GEMM_SPLIT_BF16") ? std::atoi(std::getenv("JIRF_GEMM_SPLIT_BF16")) != 0 : 1};
   return on;
 }
-bool gemm_split_bf16_covers(int K) { return K % 16 == 0 && K <= 96 && K != 80; }
+bool gemm_split_bf16_enabled() { return split_flag().load(std::memory_order_relaxed) != 0; }
+extern "C" int jirf_set_gemm_split_bf16(int enable) { return split_flag().exchange(enable != 0); }
+bool gemm_split_bf16_covers(int K) { return K == 32 || K == 48 || K == 64 || K == 96; }
 
 static uint16_t bf16_rne(float v) {
   uint32_t u;
@@ -241,12 +228,15 @@ size_t pack_wt_split3(const float* w, int M, int K, int Mpad, std::vector<uint16
 }
 
 // LayerNorm or plain 1x1 GEMM with a plain store; false when the shape is not one this kernel is built for.
-bool try_launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
-  if (!a.wt3 || a.wt_bs != 0 || a.epi != EP_STORE || a.k_split > 0) return false;
+bool gemm_b3_covers(const GemmArgs& a, int loader) {
+  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || a.epi != EP_STORE || a.k_split > 0) return false;
   if (loader != LD_LN && loader != LD_PLAIN) return false;
   if (!gemm_split_bf16_covers(a.K)) return false;
   if (loader == LD_LN && a.lnw) return false;   // the affine part must be folded into the weights
-  if ((long)a.M * a.P * 4 > 0x7fffffffL || (long)a.K * a.P * 4 > 0x7fffffffL) return false;
+  return (long)a.M * a.P * 4 <= 0x7fffffffL && (long)a.K * a.P * 4 <= 0x7fffffffL;
+}
+
+void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
   const int tiles_n = (a.P + B3_BN - 1) / B3_BN;
   const size_t smem = (size_t)((a.M + 31) / 32 * 32) * sizeof(float);
   const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * B3_WAVES);
@@ -260,11 +250,10 @@ bool try_launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
     JIRF_B3_CASE(3);
     JIRF_B3_CASE(4);
     JIRF_B3_CASE(6);
-    default: return false;
+    default: JIRF_REQUIRE(false, JIRF_EINVAL, "launch_gemm_b3: K=%d", a.K);
   }
 #undef JIRF_B3_CASE
   JIRF_HIP_CHECK(hipGetLastError());
-  return true;
 }
 
 }  // namespace jirf

@@ -184,7 +184,7 @@ PackedW pack_upload_1x1(WeightPool& pool, const float* w, const float* bias, int
   out.wt = pool.upload(packed);
   out.bias = bias ? pool.upload(bias, M) : nullptr;
   out.M = M; out.K = K; out.Cin = K;
-  if (gemm_split_bf16_enabled() && gemm_split_bf16_covers(K)) {
+  if (gemm_split_bf16_enabled()) {
     std::vector<uint16_t> planes;
     out.wt3_plane = (long)pack_wt_split3(w, M, K, out.Mpad, planes);
     // uploaded through the float pool: two bf16 per float slot

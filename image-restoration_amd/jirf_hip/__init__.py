@@ -91,6 +91,7 @@ SIGNATURES = {
     "jirf_train_window_attention_bwd": (_i, [_fp, _l, _fp, _fp, _fp, _l, _fp, _l, _fp, _fp, _i, _i, _i, _i, _i, _i, _i,
                                              _i, _vp]),
     "jirf_op_gelu_error_scan": (_i, [C.c_float, C.POINTER(C.c_double), _vp]),
+    "jirf_set_gemm_split_bf16": (_i, [_i]),
     "jirf_op_conv3x3": (_i, [_fp, _vp, _vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_dwconv3x3": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "jirf_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

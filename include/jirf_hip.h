@@ -174,6 +174,15 @@ int jirf_op_ln_conv1x1_static(const float* x, const float* ln_w, const float* ln
  * [0] |2^-(...) form - erfc(u / sqrt 2)| against float64, [1] |gelu - float64 gelu|, [2] the same for v >= 0 in units of
  * the float spacing at the exact value, [3] |gelu - the erff form|.  Synchronises `stream`. */
 int jirf_op_gelu_error_scan(float hi, double* out4_host, void* stream);
+/* Arithmetic of the matrix-bound fp32 GEMMs (1x1 and dense kxk convolutions with shared weights; no counterpart in
+ * the reference, whose nn.Conv2d is plain fp32).  1 (the default; JIRF_GEMM_SPLIT_BF16=0 in the environment starts
+ * with 0): every fp32 operand is written exactly as the sum of three bf16 values and the six largest of the nine
+ * partial products, each exact, are accumulated in fp32 on the bf16 matrix cores; the error against a float64
+ * product is that of the fp32 matrix instruction or lower (tests/test_split_bf16_gpu.py).  0: v_mfma_f32_32x32x2_f32.
+ * The setting is read when a network packs its weights and at every launch: set it before jirf_net_finalize
+ * (which packs) and leave it alone while networks packed under the other setting run (one packed with 0 keeps the
+ * fp32 instruction whatever the setting).  Returns the previous setting. */
+int jirf_set_gemm_split_bf16(int enable);
 /* Dense 3x3, stride 1, zero pad 1 (hint_arch.py:441-448,459-466,479-486,648-655).
  * w_host [Cout,Cin,3,3].  mode 0: plain; 1: followed by pixel-unshuffle(2)
  * (hint_arch.py:35-56); 2: followed by pixel-shuffle(2); res (NULL or [B,Cout,H,W]) is

@@ -8,7 +8,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [(32, 96, 510, 65536), (32, 96, 288, 65536), (32, 96, 510, 16384), (32, 48, 254, 65536), (1, 96, 510, 65536)]
+SHAPES = [("ln", 32, 96, 510, 65536), ("ln", 32, 96, 288, 65536), ("ln", 32, 96, 510, 16384), ("ln", 32, 48, 254, 65536),
+          ("ln", 1, 96, 510, 65536), ("ln", 32, 192, 1020, 4096), ("ln", 32, 192, 576, 4096), ("ln", 32, 384, 2042, 1024),
+          ("ln", 32, 384, 1152, 1024), ("res", 32, 510, 192, 4096), ("res", 32, 1021, 384, 1024), ("res", 32, 384, 192, 4096),
+          ("res", 32, 768, 384, 1024), ("res", 32, 192, 192, 4096), ("res", 32, 384, 384, 1024)]
+if os.environ.get("GEMM_SPLIT_SHAPES"):
+    SHAPES = [t for t in SHAPES if t[0] in os.environ["GEMM_SPLIT_SHAPES"].split(",")]
 
 
 def child():
@@ -28,15 +33,20 @@ def child():
         return [(names[i].decode(), ms[i], fl[i], by[i], ln[i]) for i in range(n.value)]
 
     out = {}
-    for (B, Cin, Cout, P) in SHAPES:
+    for (kind, B, Cin, Cout, P) in SHAPES:
         x = torch.randn(B, Cin, P, device="cuda") * 2 + 0.5
         y = torch.empty(B, Cout, P, device="cuda")
         w = np.ascontiguousarray((rng.standard_normal((Cout, Cin)) * Cin ** -0.5).astype(np.float32))
         lw = np.ascontiguousarray((1 + 0.1 * rng.standard_normal(Cin)).astype(np.float32))
         lb = np.ascontiguousarray((0.1 * rng.standard_normal(Cin)).astype(np.float32))
         lwd, lbd = torch.from_numpy(lw).cuda(), torch.from_numpy(lb).cuda()
-        run = lambda: jirf_hip.check(L.jirf_op_ln_conv1x1(C.c_void_p(x.data_ptr()), C.c_void_p(lwd.data_ptr()), C.c_void_p(lbd.data_ptr()), 1,
-                                                          hp(w), C.c_void_p(y.data_ptr()), B, Cin, Cout, P, None))
+        res = torch.randn(B, Cout, P, device="cuda") if kind == "res" else None
+        if kind == "ln":
+            run = lambda: jirf_hip.check(L.jirf_op_ln_conv1x1(C.c_void_p(x.data_ptr()), C.c_void_p(lwd.data_ptr()), C.c_void_p(lbd.data_ptr()), 1,
+                                                              hp(w), C.c_void_p(y.data_ptr()), B, Cin, Cout, P, None))
+        else:
+            run = lambda: jirf_hip.check(L.jirf_op_conv1x1(C.c_void_p(x.data_ptr()), hp(w), None, C.c_void_p(res.data_ptr()),
+                                                           C.c_void_p(y.data_ptr()), B, Cin, Cout, P, None))
         for _ in range(2):
             run()
         jirf_hip.check(L.jirf_train_kernel_timing(1))
@@ -47,12 +57,16 @@ def child():
         jirf_hip.check(L.jirf_train_kernel_timing(0))
         name, ms, fl, by, n = t[0]
         # accuracy on the first image's first 4096 pixels against float64
-        xs = x[0, :, :4096].double().cpu().numpy()
-        mu = xs.mean(0, keepdims=True)
-        nrm = (xs - mu) / np.sqrt(xs.var(0, keepdims=True) + 1e-5) * lw[:, None] + lb[:, None]
-        ref = w.astype(np.float64) @ nrm
-        err = float(np.abs(y[0, :, :4096].double().cpu().numpy() - ref).max())
-        out[f"{B}x{Cin}->{Cout}x{P}"] = dict(us=ms / n * 1e3, tflops=fl / (ms / 1e3) / 1e12, gbs=by / (ms / 1e3) / 1e9, err=err, label=name)
+        npx = min(P, 4096)
+        xs = x[0, :, :npx].double().cpu().numpy()
+        if kind == "ln":
+            mu = xs.mean(0, keepdims=True)
+            nrm = (xs - mu) / np.sqrt(xs.var(0, keepdims=True) + 1e-5) * lw[:, None] + lb[:, None]
+            ref = w.astype(np.float64) @ nrm
+        else:
+            ref = w.astype(np.float64) @ xs + res[0, :, :npx].double().cpu().numpy()
+        err = float(np.abs(y[0, :, :npx].double().cpu().numpy() - ref).max())
+        out[f"{kind} {B}x{Cin}->{Cout}x{P}"] = dict(us=ms / n * 1e3, tflops=fl / (ms / 1e3) / 1e12, gbs=by / (ms / 1e3) / 1e9, err=err, label=name)
     print(json.dumps(out))
 
 

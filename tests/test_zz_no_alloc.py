@@ -1,8 +1,10 @@
 """The entry point that allocates nothing (jirf_op_ln_conv1x1_static) against the entry point it is a
-variant of (jirf_op_ln_conv1x1), through the C ABI.  Both run the same kernels on the same packed
-weights, so the outputs must be bit-identical; the static one keeps the packed weights and the
-LayerNorm statistics in the library's per-GPU device array, which keeps its contents between calls —
-hence the call pairs below, the second of each with a smaller problem."""
+variant of (jirf_op_ln_conv1x1), through the C ABI.  With the allocating entry point on the fp32 matrix
+instruction (jirf_set_gemm_split_bf16(0): the static one packs fp32 weights only, it has no room for the
+three bf16 planes of the split form) both run the same kernels on the same packed weights, so the outputs
+must be bit-identical; against the split form the two agree to fp32 rounding.  The static one keeps the
+packed weights and the LayerNorm statistics in the library's per-GPU device array, which keeps its
+contents between calls — hence the call pairs below, the second of each with a smaller problem."""
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,17 @@ import jirf_hip
 from tests.gpu_util import call, dev, hptr, ptr, stream
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def fp32_matrix_instruction(request):
+    """Every test here but the one that names the split form compares like with like."""
+    if "split" in request.node.name:
+        yield
+        return
+    before = jirf_hip.lib().jirf_set_gemm_split_bf16(0)
+    yield
+    jirf_hip.lib().jirf_set_gemm_split_bf16(before)
 
 
 def _both(kind, B, C, Cout, P, seed):
@@ -41,6 +54,19 @@ def test_static_entry_point_matches_and_survives_a_smaller_second_call(kind, fir
         got, want = _both(kind, B, C, Cout, P, seed=7 + i)
         assert np.isfinite(want).all()
         assert np.array_equal(got, want), f"call {i}: max |diff| = {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("shape", [(2, 384, 1020, 4096), (2, 96, 510, 4096), (1, 192, 576, 16384)])
+def test_static_entry_point_agrees_with_the_split_form(shape):
+    """The allocating entry point on its default arithmetic (three bf16 terms per operand, six exact partial
+    products, fp32 accumulation) against the static one (fp32 matrix instruction): fp32 rounding apart."""
+    before = jirf_hip.lib().jirf_set_gemm_split_bf16(1)
+    try:
+        got, want = _both(1, *shape, seed=5)
+    finally:
+        jirf_hip.lib().jirf_set_gemm_split_bf16(before)
+    assert np.isfinite(want).all()
+    assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()   # |y| ~ 5: a few units in the last place
 
 
 def test_static_entry_point_rejects_sizes_beyond_its_array():
