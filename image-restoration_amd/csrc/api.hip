@@ -448,7 +448,8 @@ int jirf_op_conv3x3(const float* x, const float* w_host, const float* bias_host,
     const PackedW w = pack_upload_3x3(pool, w_host, bias_host, Cout, Cin);
     const long P = (long)H * W;
     GemmArgs g{};
-    g.B = B; g.M = Cout; g.K = 9 * Cin; g.P = (int)P; g.Mpad = w.Mpad; g.wt = w.wt; g.bias = w.bias;
+    g.B = B; g.M = Cout; g.K = 9 * Cin; g.P = (int)P; g.Mpad = w.Mpad; g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane;
+    g.bias = w.bias;
     g.x = tv(const_cast<float*>(x), (long)Cin * P);
     g.y = tv(y, (long)Cout * P);  // same element count in all three modes
     g.H = H; g.W = W; g.Cin = Cin; g.imgs_per_group = 1;

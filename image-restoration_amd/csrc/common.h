@@ -128,6 +128,8 @@ bool gemm_split_bf16_covers(int K);
 // [plane][Kp / 8][Mpad][8]: the 8 consecutive k of one MFMA operand are one 16-byte word per row.
 // Returns elements per plane.
 size_t pack_wt_split3(const float* w, int M, int K, int Mpad, std::vector<uint16_t>& out);
+// the same from a K-major packed matrix [Kp][Mpad] (any of the packers below)
+size_t pack_split3_kmajor(const std::vector<float>& packed, int Kp, int Mpad, std::vector<uint16_t>& out);
 // split-bf16 GEMM with the pixel operand in registers (gemm_split.hip): whether it serves this launch, and the launch
 bool gemm_b3_covers(const GemmArgs& a, int loader);
 void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s);

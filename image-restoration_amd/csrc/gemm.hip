@@ -535,12 +535,37 @@ __global__ __launch_bounds__(256, 3) void gemm_t3_kernel(const GemmArgs a, const
     ln_rs = a.rstd[(long)b * P + pcl];
   }
 
+  // implicit k x k convolution: k = tap * Cin + c with Cin % 8 == 0, so the eight k of a fetch share one tap (a
+  // scalar) and are eight adjacent input planes; the thread's input coordinate moves with the tap, the plane
+  // advance is the scalar offset, and a tap that falls into the zero padding is an out-of-range offset: reads 0.
+  int cv_y = 0, cv_x = 0;
+  __amdgpu_buffer_rsrc_t cv_rsrc = x_rsrc;
+  if constexpr (LOADER == LD_CONV3) {
+    const int yy = pcl / a.W;
+    cv_y = yy * a.stride - a.pad;
+    cv_x = (pcl - yy * a.W) * a.stride - a.pad;
+    cv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0,
+                                                (int)min((long)a.Cin * a.Hin * a.Win * 4, 0x7fffffffL), 0x00020000);
+  }
+
   u32x4 wa[3];
   float raw[8];
   auto fetch = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) wa[i] = W3[i * plane16 + (2 * kt + g) * a.Mpad];
     const int k0 = 16 * kt + 8 * g;              // wave-uniform: the row advance is a scalar offset
+    if constexpr (LOADER == LD_CONV3) {
+      const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+      const int ky = tap / a.ks, kx = tap - ky * a.ks;
+      const int iy = cv_y + ky, ix = cv_x + kx;
+      const bool ok = k0 < K && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      const int voff = ok ? (iy * a.Win + ix) * 4 : 0x7fffffff;
+      const int plane_b = a.Hin * a.Win * 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        raw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cv_rsrc, voff, (c0 + i) * plane_b, 0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = k0 + i;
@@ -637,6 +662,12 @@ __global__ __launch_bounds__(256, 3) void gemm_t3_kernel(const GemmArgs a, const
   const int epi = a.epi;
   if constexpr (LOADER == LD_LN) {
     run_epilogue(std::integral_constant<int, EP_STORE>{});
+  } else if constexpr (LOADER == LD_CONV3) {
+    if (epi == EP_UNSHUFFLE) run_epilogue(std::integral_constant<int, EP_UNSHUFFLE>{});
+    else if (epi == EP_SHUFFLE) run_epilogue(std::integral_constant<int, EP_SHUFFLE>{});
+    else if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
+    else if (epi == EP_LEAKY) run_epilogue(std::integral_constant<int, EP_LEAKY>{});
+    else run_epilogue(std::integral_constant<int, EP_STORE>{});
   } else {
     if (epi == EP_RESID) run_epilogue(std::integral_constant<int, EP_RESID>{});
     else if (epi == EP_GELU_MUL) run_epilogue(std::integral_constant<int, EP_GELU_MUL>{});
@@ -1323,10 +1354,14 @@ static bool try_launch_ws(const GemmArgs& a, int loader, bool vec, hipStream_t s
 // the split-bf16 K-loop kernel: long reductions on grids that fill the chip, shared weights
 static bool t3_covers(const GemmArgs& a, int loader) {
   if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0) return false;
-  if (loader != LD_PLAIN && loader != LD_LN) return false;
+  if (loader != LD_PLAIN && loader != LD_LN && loader != LD_CONV3) return false;
   if (loader == LD_LN && (!a.mu || !a.rstd)) return false;
-  if (a.M < 128 || a.K <= 96) return false;
-  if ((long)a.K * a.P * 4 > 0x7fffffffL) return false;
+  if (a.K <= 96) return false;
+  if (loader == LD_CONV3) {
+    if (a.M < 96 || a.Cin % 8 != 0 || (long)a.Cin * a.Hin * a.Win * 4 > 0x7fffffffL) return false;
+  } else if (a.M < 128 || (long)a.K * a.P * 4 > 0x7fffffffL) {
+    return false;
+  }
   return (long)((a.M + T3_B - 1) / T3_B) * ((a.P + T3_B - 1) / T3_B) * a.B >= 512;
 }
 static void launch_t3(const GemmArgs& a, int loader, hipStream_t s) {
@@ -1334,6 +1369,7 @@ static void launch_t3(const GemmArgs& a, int loader, hipStream_t s) {
   const long blocks = (long)tiles_m * tiles_n * a.B;
   const dim3 grid((unsigned)blocks), block(256);
   if (loader == LD_LN) hipLaunchKernelGGL((gemm_t3_kernel<LD_LN>), grid, block, 0, s, a, tiles_m, tiles_n);
+  else if (loader == LD_CONV3) hipLaunchKernelGGL((gemm_t3_kernel<LD_CONV3>), grid, block, 0, s, a, tiles_m, tiles_n);
   else hipLaunchKernelGGL((gemm_t3_kernel<LD_PLAIN>), grid, block, 0, s, a, tiles_m, tiles_n);
   JIRF_HIP_CHECK(hipGetLastError());
 }

@@ -227,6 +227,22 @@ size_t pack_wt_split3(const float* w, int M, int K, int Mpad, std::vector<uint16
   return plane;
 }
 
+size_t pack_split3_kmajor(const std::vector<float>& packed, int Kp, int Mpad, std::vector<uint16_t>& out) {
+  const size_t plane = (size_t)Kp * Mpad;
+  out.assign(3 * plane, 0);
+  for (int k = 0; k < Kp; ++k)
+    for (int o = 0; o < Mpad; ++o) {
+      const float v = packed[(size_t)k * Mpad + o];
+      const uint16_t h = bf16_rne(v);
+      const float r1 = v - bf16_to_f32(h);
+      const uint16_t m = bf16_rne(r1);
+      const uint16_t l = bf16_rne(r1 - bf16_to_f32(m));
+      const size_t at = ((size_t)(k / 8) * Mpad + o) * 8 + (k % 8);
+      out[at] = h; out[plane + at] = m; out[2 * plane + at] = l;
+    }
+  return plane;
+}
+
 // LayerNorm or plain 1x1 GEMM with a plain store; false when the shape is not one this kernel is built for.
 bool gemm_b3_covers(const GemmArgs& a, int loader) {
   if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || a.epi != EP_STORE || a.k_split > 0) return false;

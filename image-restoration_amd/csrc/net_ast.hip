@@ -304,7 +304,7 @@ class AstNet final : public Net {
     g.H = (Hin + 2 * pad - ks) / stride + 1;
     g.W = (Win + 2 * pad - ks) / stride + 1;
     g.B = B; g.M = w.M; g.K = w.K; g.P = g.H * g.W; g.Mpad = w.Mpad;
-    g.wt = w.wt; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r;
+    g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r;
     g.Cin = w.Cin; g.ks = ks; g.stride = stride; g.pad = pad; g.Hin = Hin; g.Win = Win; g.imgs_per_group = 1;
     launch_gemm(g, LD_CONV3, s);
   }

@@ -255,7 +255,7 @@ class Astv2Net final : public Net {
     GemmArgs g{};
     g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
     g.B = B; g.M = w.M; g.K = w.K; g.P = H * W; g.Mpad = w.Mpad;
-    g.wt = w.wt; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r;
+    g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane; g.bias = w.bias; g.x = x; g.y = y; g.epi = epi; g.r = r;
     g.H = H; g.W = W; g.Cin = w.Cin; g.imgs_per_group = 1;
     launch_gemm(g, LD_CONV3, s);
   }

@@ -210,10 +210,16 @@ PackedW pack_upload_ln_1x1(WeightPool& pool, const float* w, const float* bias, 
 PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, int M, int Cin, int ks) {
   std::vector<float> packed;
   PackedW out;
-  pack_wt_conv(w, M, Cin, ks, packed, &out.Mpad);
+  const int kp = pack_wt_conv(w, M, Cin, ks, packed, &out.Mpad);
   out.wt = pool.upload(packed);
   out.bias = bias ? pool.upload(bias, M) : nullptr;
   out.M = M; out.K = ks * ks * Cin; out.Cin = Cin;
+  if (gemm_split_bf16_enabled() && Cin % 8 == 0 && M >= 96) {   // what the split K-loop kernel's conv loader takes
+    std::vector<uint16_t> planes;
+    out.wt3_plane = (long)pack_split3_kmajor(packed, kp, out.Mpad, planes);
+    planes.resize((planes.size() + 1) / 2 * 2, 0);
+    out.wt3 = reinterpret_cast<const uint16_t*>(pool.upload(reinterpret_cast<const float*>(planes.data()), planes.size() / 2));
+  }
   return out;
 }
 PackedW pack_upload_3x3(WeightPool& pool, const float* w, const float* bias, int M, int Cin) {
