@@ -566,27 +566,22 @@ __global__ __launch_bounds__(256, 3) void gemm_t3_kernel(const GemmArgs a, const
         raw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cv_rsrc, voff, (c0 + i) * plane_b, 0));
       return;
     }
+    // rows past K read as zero through an out-of-range offset (their weights are zero padding; no branch)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = k0 + i;
-      float v = 0.f;
-      if (k < K) {                               // rows past K stay zero (their weights are zero padding)
-        if (LOADER == LD_PLAIN && k < a.k_split) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x2_rsrc, x_voff, k * P * 4, 0));
-        else v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_voff, k * P * 4, 0));
-      }
-      raw[i] = v;
+      const int vo = k < K ? x_voff : 0x7fffffff;
+      if (LOADER == LD_PLAIN && a.k_split > 0)
+        raw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(k < a.k_split ? x2_rsrc : x_rsrc, vo, min(k, K - 1) * P * 4, 0));
+      else
+        raw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, vo, min(k, K - 1) * P * 4, 0));
     }
   };
   auto stage = [&](int kt, int buf) {
-    if constexpr (LOADER == LD_LN) {
+    if constexpr (LOADER == LD_LN) {   // (the affine part is folded into the weights)
       const int k0 = 16 * kt + 8 * g;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = k0 + i;
-        float v = (raw[i] - ln_mu) * ln_rs;
-        if (a.lnw) v = v * a.lnw[min(k, K - 1)] + (a.lnb ? a.lnb[min(k, K - 1)] : 0.f);
-        raw[i] = k < K ? v : 0.f;
-      }
+      for (int i = 0; i < 8; ++i) raw[i] = k0 + i < K ? (raw[i] - ln_mu) * ln_rs : 0.f;
     }
     bf16x8 h, m, l;
     split8(raw, h, m, l);
@@ -1355,7 +1350,7 @@ static bool try_launch_ws(const GemmArgs& a, int loader, bool vec, hipStream_t s
 static bool t3_covers(const GemmArgs& a, int loader) {
   if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0) return false;
   if (loader != LD_PLAIN && loader != LD_LN && loader != LD_CONV3) return false;
-  if (loader == LD_LN && (!a.mu || !a.rstd)) return false;
+  if (loader == LD_LN && (!a.mu || !a.rstd || a.lnw)) return false;   // the affine part must be folded into the weights
   if (a.K <= 96) return false;
   if (loader == LD_CONV3) {
     if (a.M < 96 || a.Cin % 8 != 0 || (long)a.Cin * a.Hin * a.Win * 4 > 0x7fffffffL) return false;
@@ -1559,7 +1554,8 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   static const bool tile_forced_early = std::getenv("JIRF_GEMM_TILE") != nullptr;
   const bool xs_shape = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
                         (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
-  const int split_kind = tile_forced_early ? 0 : (xs_shape && gemm_b3_covers(a, loader)) ? 1 : t3_covers(a, loader) ? 2 : 0;
+  const int split_kind = tile_forced_early ? 0 : (xs_shape && gemm_b3_covers(a, loader)) ? 1 : t3_covers(a, loader) ? 2
+                         : (!xs_shape && gemm_k3_covers(a, loader)) ? 3 : 0;
   Scope sc(intern_label("%s%s M%d K%d P%d", name, split_kind ? "_bf16x3" : "", a.M, a.K, a.P), flops, bytes, s);
 
   // the RGB output convolutions: a handful of output rows would idle the matrix cores
@@ -1579,6 +1575,7 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
                   (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
   if (split_kind == 1) return launch_gemm_b3(a, loader, s);
   if (split_kind == 2) return launch_t3(a, loader, s);
+  if (split_kind == 3) return launch_gemm_k3(a, s);
   if (!xs && try_launch_ws(a, loader, vec, s)) return;
   if (xs) {
     // 128-pixel tiles need K <= 128 (LDS) and enough of them: an underfilled grid does better with 64-pixel

@@ -186,6 +186,149 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same idea turned round for short OUTPUTS (M <= 96, any reduction length: the project_out / gate GEMMs, whose
+// input is several times wider than their output).  A wave still owns 32 pixels, but now keeps the accumulators
+// of all its output rows (up to three 32-row tiles) and walks over the reduction in chunks of 32: the chunk's 16
+// channels per lane are loaded a chunk ahead, split on arrival, and meet the chunk's weights (every output row x
+// 32 k x three planes, at most 18 KiB) in LDS.  No store happens inside the loop, so the loads' wait costs nothing
+// extra; bias, residual or gate, and the stores come once at the end.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int EPI>
+__global__ __launch_bounds__(64 * B3_WAVES, 3) void gemm_k3_kernel(const GemmArgs a, const int tiles_n) {
+  constexpr int R = NT * 32;                    // weight rows per k group
+  constexpr int CH = 3 * 4 * R;                 // 16-byte slots of one chunk (plane, k group, row)
+  constexpr int PIECES = CH / 64;
+  constexpr int PW = (PIECES + B3_WAVES - 1) / B3_WAVES;
+  __shared__ __attribute__((aligned(16))) u32x4 Abuf[2][CH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / tiles_n;
+  const int n0 = (blockIdx.x - b * tiles_n) * B3_BN;
+  const int P = a.P, M = a.M, K = a.K;
+  const int nch = (K + 31) >> 5;
+
+  const u32x4* __restrict__ W3 = reinterpret_cast<const u32x4*>(a.wt3);
+  const int plane16 = (int)(a.wt3_plane / 8);
+  const u32x4* w_src[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int q = min((wave + i * B3_WAVES) * 64 + lane, CH - 1);
+    const int pl = q / (4 * R), g = (q / R) & 3, m = q % R;
+    w_src[i] = W3 + pl * plane16 + g * a.Mpad + min(m, a.Mpad - 1);
+  }
+  const unsigned abuf0 = (unsigned)(uintptr_t)&Abuf[0][0];
+  auto copy_chunk = [&](int kc, int buf) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i)
+      if (PIECES % B3_WAVES == 0 || wave + i * B3_WAVES < PIECES)   // wave-uniform
+        dma16(w_src[i] + (long)kc * 4 * a.Mpad, abuf0 + (unsigned)(buf * CH + (wave + i * B3_WAVES) * 64) * 16u);
+  };
+
+  const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)min((long)K * P * 4, 0x7fffffffL), 0x00020000);
+  const int pix = n0 + wave * 32 + l31;
+  const int OOB = 0x7fffffff;
+  const int x_voff = (8 * half * P + min(pix, P - 1)) * 4;
+  float raw[2][8];
+  auto fetch = [&](int kc) {   // channels 32 kc + 16 s + 8 half + i; rows past K read as zero (out-of-range offset)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 32 * kc + 16 * s + i;      // (+ 8 half in the lane part)
+        const int vo = k + 8 * half < K ? x_voff : OOB;
+        raw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, vo, min(k, K - 1) * P * 4, 0));
+      }
+  };
+  copy_chunk(0, 0);
+  fetch(0);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  bf16x8 Bh[2], Bm[2], Bl[2];
+  split8(raw[0], Bh[0], Bm[0], Bl[0]);           // (the compiler waits for the loads here)
+  split8(raw[1], Bh[1], Bm[1], Bl[1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk 0 of the weights is in LDS
+  __syncthreads();
+
+  for (int kc = 0; kc < nch; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nch) {
+      copy_chunk(kc + 1, buf ^ 1);
+      fetch(kc + 1);
+    }
+    const bf16x8* __restrict__ Ab = reinterpret_cast<const bf16x8*>(&Abuf[buf][half * R + l31]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[NT], am[NT], al[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        ah[t] = Ab[(0 * 4 + 2 * s) * R + t * 32];
+        am[t] = Ab[(1 * 4 + 2 * s) * R + t * 32];
+        al[t] = Ab[(2 * 4 + 2 * s) * R + t * 32];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], Bm[s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], Bh[s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], Bl[s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], Bh[s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], Bm[s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], Bh[s], acc[t], 0, 0, 0);
+    }
+    if (kc + 1 < nch) {
+      split8(raw[0], Bh[0], Bm[0], Bl[0]);
+      split8(raw[1], Bh[1], Bm[1], Bl[1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next weight chunk has landed
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, residual or gate, store -------------------------------------------------------------
+  float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
+  const __amdgpu_buffer_rsrc_t y_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
+  const int pv = pix < P ? (4 * half * P + pix) * 4 : OOB;
+  __amdgpu_buffer_rsrc_t r_rsrc = y_rsrc;
+  if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL)
+    r_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.r.p + (long)b * a.r.bs, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
+  const float* __restrict__ bias = a.bias ? a.bias + (long)b * a.bias_bs : nullptr;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int m0 = t * 32;
+    if (m0 >= M) continue;
+    float aux[16], bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2);
+      const int vo = row + 4 * half < M ? pv : OOB;    // rows past M: nothing read, nothing stored
+      bv[r] = bias ? bias[min(row + 4 * half, M - 1)] : 0.f;
+      if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL)
+        aux[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vo, min(row, M - 1) * P * 4, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2);
+      const int vo = row + 4 * half < M ? pv : OOB;
+      float v = acc[t][r] + bv[r];
+      if constexpr (EPI == EP_RESID) v += aux[r];
+      if constexpr (EPI == EP_GELU_MUL) v = gelu_fast(v) * aux[r];
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, vo, min(row, M - 1) * P * 4, 0);
+    }
+  }
+}
+
 }  // namespace
 
 static std::atomic<int>& split_flag() {
@@ -269,6 +412,33 @@ void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
     default: JIRF_REQUIRE(false, JIRF_EINVAL, "launch_gemm_b3: K=%d", a.K);
   }
 #undef JIRF_B3_CASE
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
+// short outputs: M <= 96, the reduction a multiple of 32 after padding, plain store / residual / GELU gate
+bool gemm_k3_covers(const GemmArgs& a, int loader) {
+  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || loader != LD_PLAIN || a.k_split > 0) return false;
+  if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_GELU_MUL) return false;
+  const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
+  if (a.M > 96 || a.K < 96 || Kp % 32 != 0) return false;
+  if ((long)((a.P + B3_BN - 1) / B3_BN) * a.B < 512) return false;     // a grid that fills the chip
+  return (long)a.M * a.P * 4 <= 0x7fffffffL && (long)a.K * a.P * 4 <= 0x7fffffffL;
+}
+
+void launch_gemm_k3(const GemmArgs& a, hipStream_t s) {
+  const int tiles_n = (a.P + B3_BN - 1) / B3_BN;
+  const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * B3_WAVES);
+  const int NT = (a.M + 31) / 32;
+#define JIRF_K3_EPI(N)                                                                                              \
+  do {                                                                                                              \
+    if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID>), grid, block, 0, s, a, tiles_n);        \
+    else if (a.epi == EP_GELU_MUL) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_GELU_MUL>), grid, block, 0, s, a, tiles_n); \
+    else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE>), grid, block, 0, s, a, tiles_n);                          \
+  } while (0)
+  if (NT == 1) JIRF_K3_EPI(1);
+  else if (NT == 2) JIRF_K3_EPI(2);
+  else JIRF_K3_EPI(3);
+#undef JIRF_K3_EPI
   JIRF_HIP_CHECK(hipGetLastError());
 }
 

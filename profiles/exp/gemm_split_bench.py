@@ -11,7 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 SHAPES = [("ln", 32, 96, 510, 65536), ("ln", 32, 96, 288, 65536), ("ln", 32, 96, 510, 16384), ("ln", 32, 48, 254, 65536),
           ("ln", 1, 96, 510, 65536), ("ln", 32, 192, 1020, 4096), ("ln", 32, 192, 576, 4096), ("ln", 32, 384, 2042, 1024),
           ("ln", 32, 384, 1152, 1024), ("res", 32, 510, 192, 4096), ("res", 32, 1021, 384, 1024), ("res", 32, 384, 192, 4096),
-          ("res", 32, 768, 384, 1024), ("res", 32, 192, 192, 4096), ("res", 32, 384, 384, 1024)]
+          ("res", 32, 768, 384, 1024), ("res", 32, 192, 192, 4096), ("res", 32, 384, 384, 1024),
+          ("res", 32, 255, 96, 65536), ("res", 32, 192, 96, 65536), ("res", 32, 255, 96, 16384), ("res", 32, 127, 48, 65536),
+          ("res", 32, 96, 96, 65536), ("res", 1, 255, 96, 65536)]
+if os.environ.get("GEMM_SPLIT_IDX"):
+    SHAPES = [SHAPES[int(i)] for i in os.environ["GEMM_SPLIT_IDX"].split(",")]
 if os.environ.get("GEMM_SPLIT_SHAPES"):
     SHAPES = [t for t in SHAPES if t[0] in os.environ["GEMM_SPLIT_SHAPES"].split(",")]
 

@@ -16,7 +16,9 @@ def main():
     # reduction lengths the split kernel covers (32, 48, 64, 96; ragged pixel counts and output-row tails), and one it
     # does not (127: both runs then use the same fp32 kernel)
     for (B, C, Cout, P) in [(2, 48, 254, 4096), (1, 96, 510, 4100), (2, 96, 288, 777), (1, 64, 170, 1000), (1, 32, 96, 333),
-                            (1, 127, 48, 1000)]:
+                            (1, 127, 48, 1000),
+                            # short outputs over a long reduction (the chunked form; it wants a grid that fills the chip)
+                            (1, 255, 96, 65536), (1, 127, 48, 70001), (2, 192, 80, 32768)]:
         x = rng.standard_normal((B, C, P)).astype(np.float32) * 2 + 0.5
         w = (rng.standard_normal((Cout, C)) * C ** -0.5).astype(np.float32)
         res = rng.standard_normal((B, Cout, P)).astype(np.float32)
