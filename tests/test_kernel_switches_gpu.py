@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"JIRF_GEMM_TILE": "2"},                                  # ... 64 x 128 (the default only picks it at large batches)
     {"JIRF_GEMM_TILE": "1"},                                  # ... 128 x 128
     {"JIRF_GEMM_TILE": "0"},                                  # ... 96 x 128
-    {"JIRF_GEMM_SPLIT_BF16": "1"},                            # split-bf16 activation-stationary GEMM
+    {"JIRF_GEMM_SPLIT_BF16": "0"},                            # every GEMM on the fp32 matrix instruction (split-bf16 forms off)
 ])
 def test_golden_cases_with_switches(switches):
     env = dict(os.environ, **switches)
