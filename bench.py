@@ -65,13 +65,14 @@ def hint_flops_per_image(cfg, h, w):
 
 
 def kernel_source_digest():
-    """sha256 over the GEMM kernel source and the argument structure it is launched with: the PMC traffic
+    """sha256 over the GEMM kernel sources and the argument structure they are launched with: the PMC traffic
     record under profiles/ is only valid for the code it was measured on."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "image-restoration_amd", "csrc")
-    with open(os.path.join(src, "gemm.hip"), "rb") as fh:
-        h.update(fh.read())
+    for f in ("gemm.hip", "gemm_split.hip", "split_bf16.h"):
+        with open(os.path.join(src, f), "rb") as fh:
+            h.update(fh.read())
     with open(os.path.join(src, "common.h")) as fh:
         text = fh.read()
     h.update(text[text.index("struct GemmArgs {"):text.index("void launch_gemm(")].encode())
@@ -394,6 +395,8 @@ def main():
                     help="hand host buffers to the library (PCIe copies inside the timed region); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-compare", action="store_true",
+                    help="skip the second network that repeats the steps on the fp32 matrix instruction (profiling runs)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the `configs` array (the other shapes of the BASELINE metric, N = 1 only)")
     ap.add_argument("--detail", default=None, help="write the per-shape kernel table to this file")
@@ -529,7 +532,7 @@ def main():
         "against float64 at or below the fp32 matrix instruction's (tests/test_split_bf16_gpu.py); the other contractions "
         "use v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64" if split_on else
         "v_mfma_f32_32x32x2_f32 (fp32 matrix instruction) for every fp32 contraction; v_mfma_f64_16x16x4_f64 for the Gram matrix")
-    if rank == 0 and world == 1 and split_on and not args.host_io and not script_path:
+    if rank == 0 and world == 1 and split_on and not args.host_io and not script_path and not args.no_fp32_compare:
         # the same steps with every GEMM on the fp32 matrix instruction (a second network, packed under that setting)
         _jh.lib().jirf_set_gemm_split_bf16(0)
         try:

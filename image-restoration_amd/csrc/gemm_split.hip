@@ -25,8 +25,6 @@
 
 namespace jirf {
 
-namespace {
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // t[l] + t[l ^ 32]: v_permlane32_swap exchanges the upper half of its first operand with the lower half of
 // its second; fed two copies of t, each lane then holds its own value in one and its partner's in the other.
@@ -328,8 +326,6 @@ __global__ __launch_bounds__(64 * B3_WAVES, 3) void gemm_k3_kernel(const GemmArg
     }
   }
 }
-
-}  // namespace
 
 static std::atomic<int>& split_flag() {
   static std::atomic<int> on{std::getenv("JIRF_GEMM_SPLIT_BF16") ? std::atoi(std::getenv("JIRF_GEMM_SPLIT_BF16")) != 0 : 1};

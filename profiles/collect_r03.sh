@@ -7,7 +7,7 @@ set -e
 out=gpurun_out/prof_r03
 mkdir -p $out
 export TMPDIR=/tmp
-common="--no-cpu-baseline --no-extra-configs"
+common="--no-cpu-baseline --no-extra-configs --no-fp32-compare"
 run_arch() {
   a=$1; shift
   timeout -k 10 200 python3 bench.py --arch $a "$@" --steps 5 --warmup 2 $common --detail $out/${a}_detail.txt > $out/${a}_bench.json

@@ -9,7 +9,8 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 32   # crops per step of the benchmark the traces were taken on
 src = f"gpurun_out/prof_{tag}"
-dst = "profiles"
+dst = os.environ.get("PROFILES_DST", "profiles")   # (on the GPU box only gpurun_out/ comes back)
+os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
@@ -101,12 +102,13 @@ if os.path.exists(p_sq):
                                   ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if c.get("SQ_WAVE_CYCLES")}}
 import hashlib
 _h = hashlib.sha256()
-with open(os.path.join("image-restoration_amd", "csrc", "gemm.hip"), "rb") as _fh:
-    _h.update(_fh.read())
+for _f in ("gemm.hip", "gemm_split.hip", "split_bf16.h"):
+    with open(os.path.join("image-restoration_amd", "csrc", _f), "rb") as _fh:
+        _h.update(_fh.read())
 with open(os.path.join("image-restoration_amd", "csrc", "common.h")) as _fh:
     _t = _fh.read()
 _h.update(_t[_t.index("struct GemmArgs {"):_t.index("void launch_gemm(")].encode())
-res = {"kernel_source_sha256": _h.hexdigest(), "isolated_kernel_trace": iso, "sq_counters": sq, "op": f"gemm_ln_1x1 M510 K96 P65536 (B={BATCH}): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
+res = {"kernel_source_sha256": _h.hexdigest(), "isolated_kernel_trace": iso, "sq_counters": sq, "op": f"gemm_ln_1x1_bf16x3 M510 K96 P65536 (B={BATCH}): LayerNorm + 1x1 conv, the dominant launch shape of the HINT benchmark",
        "algorithmic_bytes_per_launch": 4.0 * BATCH * 65536 * (96 + 510),
        "kernels": out}
 with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
