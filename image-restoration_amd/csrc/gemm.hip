@@ -6,7 +6,9 @@
 //   * dense 3x3 convolutions as an implicit GEMM over k = tap * Cin + c
 // Activations are planar ([channel][pixel], pixel contiguous), so the pixel axis sits on the
 // MFMA column (lane) index: loads and stores are 128-byte row segments.  Arithmetic is
-// v_mfma_f32_32x32x2_f32: exact fp32 fma chains, k-ordered.
+// v_mfma_f32_32x32x2_f32 (fp32 fma chains, k-ordered) in every kernel of this file but gemm_t3_kernel, which,
+// like the kernels of gemm_split.hip, forms each fp32 product from exact bf16 partial products on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (on by default; launch_gemm picks per shape).
 //
 // Tile: a workgroup of WAVES_M x WAVES_N waves, each wave owning TM x TN accumulator tiles of
 // 32 x 32; K stepped by 16 through a double-buffered LDS image [k][m] / [k][n]; operands are
