@@ -303,7 +303,7 @@ int jirf_op_ln_conv1x1(const float* x, const float* ln_w, const float* ln_b, int
     float* mu = static_cast<float*>(stats.p);
     float* rstd = mu + (size_t)B * P;
     const TV xv = tv(const_cast<float*>(x), (long)Cin * P);
-    if (!gemm_ln_inline(Cin)) launch_ln_stats(xv, mu, rstd, B, Cin, P, s);
+    if (!gemm_ln_inline(Cin, Cout, P, B)) launch_ln_stats(xv, mu, rstd, B, Cin, P, s);
     GemmArgs g{};
     g.B = B; g.M = Cout; g.K = Cin; g.P = P; g.Mpad = w.Mpad; g.wt = w.wt; g.wt3 = w.wt3; g.wt3_plane = w.wt3_plane;
     g.x = xv; g.y = tv(y, (long)Cout * P); g.imgs_per_group = 1; g.epi = EP_STORE; g.bias = w.bias;

@@ -119,6 +119,8 @@ constexpr size_t SPLITK_WS_FLOATS = (size_t)4 << 20;   // what the networks rese
 void launch_gemm(const GemmArgs& a, int loader, hipStream_t s);
 // true when the LD_LN loader computes the LayerNorm statistics itself (mu / rstd may be null)
 bool gemm_ln_inline(int K);
+// the same for one launch shape (M outputs, P pixels, B images): some shapes go to a kernel that reads the statistics
+bool gemm_ln_inline(int K, int M, int P, int B);
 // true when the split-bf16 GEMM variant is switched on (JIRF_GEMM_SPLIT_BF16=1): weights are then
 // also packed as three bf16 planes
 bool gemm_split_bf16_enabled();

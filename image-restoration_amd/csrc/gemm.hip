@@ -1375,8 +1375,15 @@ static bool xs_enabled() {
   static const bool on = !std::getenv("JIRF_GEMM_NO_XS") && !std::getenv("JIRF_GEMM_TILE");
   return on;
 }
-// (with the split-bf16 kernels on, reductions past 96 go to the K-loop form, which reads the statistics)
-bool gemm_ln_inline(int K) { return K <= 256 && xs_enabled() && !(gemm_split_bf16_enabled() && K > 96); }
+bool gemm_ln_inline(int K) { return K <= 256 && xs_enabled(); }
+// (with the split-bf16 kernels on, a reduction past 96 on a grid that fills the chip goes to the K-loop form, which
+//  reads the statistics: the same test as t3_covers, for a caller that has not built its GemmArgs yet)
+bool gemm_ln_inline(int K, int M, int P, int B) {
+  if (!gemm_ln_inline(K)) return false;
+  const bool t3 = gemm_split_bf16_enabled() && K > 96 && M >= 128 && (long)K * P * 4 <= 0x7fffffffL &&
+                  (long)((M + T3_B - 1) / T3_B) * ((P + T3_B - 1) / T3_B) * B >= 512;
+  return !t3;
+}
 
 template <int BN, int TNW>
 static void launch_xs(const GemmArgs& a_in, int loader, bool vec, hipStream_t s) {

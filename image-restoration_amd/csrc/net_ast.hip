@@ -314,10 +314,11 @@ class AstNet final : public Net {
     const TV t1 = tv(t1_, (long)t1_per_), t2 = tv(t2_, (long)t2_per_);
     if (bl.att) {
       // norm1 -> fused q|k|v projection -> window attention -> proj + shortcut
-      if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
+      if (!gemm_ln_inline(C, 3 * C, P, B)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
       GemmArgs g{};
     g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
       g.B = B; g.M = 3 * C; g.K = C; g.P = P; g.Mpad = bl.qkv.Mpad; g.wt = bl.qkv.wt; g.bias = bl.qkv.bias;
+      g.wt3 = bl.qkv.wt3; g.wt3_plane = bl.qkv.wt3_plane;
       g.x = x; g.y = t1; g.epi = EP_STORE; g.imgs_per_group = 1;
       g.mu = mu_; g.rstd = rstd_; g.lnw = nullptr; g.lnb = nullptr; g.ln_center = 1;
       launch_gemm(g, LD_LN, s);

@@ -264,7 +264,7 @@ class Astv2Net final : public Net {
     const int C = bl.C, P = H * W, h = bl.hidden;
     const TV t1 = tv(t1_, (long)t1_per_), t2 = tv(t2_, (long)t2_per_);
     if (bl.att) {
-      if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
+      if (!gemm_ln_inline(C, bl.qkv.M, P, B)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
       gemm(bl.qkv, x, t1, B, P, EP_STORE, TV{}, s, LD_LN);   // norm1 folded into bl.qkv
       launch_dwconv3x3(t1, bl.qkv_dw_w, bl.qkv_dw_b, t2, B, 3 * C, H, W, 0, s);
       HeadAttnScratch sc;

@@ -421,7 +421,7 @@ class FproNet final : public Net {
     const TV t1 = tv(t1_, (long)t1_per_), t2 = tv(t2_, (long)t2_per_);
     if (bl.att) {
       // MDTA (fpro_arch.py:128-144): rows normalised as x / (||x|| + 1e-12) (:10-12)
-      if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
+      if (!gemm_ln_inline(C, bl.qkv.M, P, B)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
       gemm(bl.qkv, x, t1, B, P, EP_STORE, TV{}, s, LD_LN);   // norm1 folded into bl.qkv
       launch_dwconv3x3(t1, bl.qkv_dw_w, bl.qkv_dw_b, t2, B, 3 * C, H, W, 0, s);
       HeadAttnScratch sc;
@@ -440,7 +440,7 @@ class FproNet final : public Net {
       gemm(bl.proj, tv_chan(t1, 0, P), x, B, P, EP_RESID, x, s);
     }
     // GDFN (fpro_arch.py:109-114)
-    if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
+    if (!gemm_ln_inline(C, bl.pin.M, P, B)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
     gemm(bl.pin, x, t1, B, P, EP_STORE, TV{}, s, LD_LN);   // norm2 folded into bl.pin
     launch_dwconv3x3(t1, bl.ffn_dw_w, bl.ffn_dw_b, t2, B, 2 * h, H, W, 1, s);
     gemm(bl.pout, t2, x, B, P, EP_RESID, x, s);

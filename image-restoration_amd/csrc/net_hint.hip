@@ -460,7 +460,7 @@ class HintNet final : public Net {
     const int C = bl.C, P = H * W, h = bl.hidden;
     const TV t1 = tv(t1_, (long)t1_per_), t2 = tv(t2_, (long)t2_per_);
     if (bl.att) {
-      if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
+      if (!gemm_ln_inline(C, bl.qkv.M, P, B)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
       gemm(bl.qkv, x, t1, B, P, EP_STORE, TV{}, s, LD_LN, &bl.n1);
       launch_dwconv3x3(t1, bl.qkv_dw.w, bl.qkv_dw.b, t2, B, 3 * C, H, W, 0, s);
       const HintAttnShape sh = hint_attn_shape(B, C, P, mode);
@@ -493,7 +493,7 @@ class HintNet final : public Net {
       gemm(bl.gate, tv_chan(t1, 2 * C, P), tv_chan(t1, 0, P), B, P, EP_GELU_MUL, tv_chan(t1, 2 * C, P), s);
       gemm(bl.tail, tv_chan(t1, 0, P), x, B, P, EP_RESID, x, s);
     }
-    if (!gemm_ln_inline(C)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
+    if (!gemm_ln_inline(C, bl.pin.M, P, B)) launch_ln_stats(x, mu_, rstd_, B, C, P, s);
     gemm(bl.pin, x, t1, B, P, EP_STORE, TV{}, s, LD_LN, &bl.n2);
     launch_dwconv3x3(t1, bl.ffn_dw.w, bl.ffn_dw.b, t2, B, 2 * h, H, W, 1, s);
     gemm(bl.pout, t2, x, B, P, EP_RESID, x, s);
