@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
         dma16(w_src[i] + mt * 32, abuf0 + (unsigned)(buf * CH + (wave + i * B3_WAVES) * 64) * 16u);
   };
   copy_chunk(0, 0);
+  if (n_mt > 1) copy_chunk(1, 1);
 
   // ---- the wave's 32 pixels: load, normalise, split ---------------------------------------------------
   const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
@@ -136,10 +137,14 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
 #pragma unroll
   for (int s = 0; s < NS; ++s) split8(raw[s], Bh[s], Bm[s], Bl[s]);
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk 0 is in LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 0 and 1 are in LDS
   __syncthreads();
 
   // ---- output tiles ------------------------------------------------------------------------------------
+  // Per tile: MFMAs, wait for the copy of the next chunk, barrier, request the chunk after next into the buffer
+  // just read, and only then the stores.  The CU's vector-memory path is one queue: a copy requested after a
+  // tile's stores waits behind them (microseconds when the chip writes at full rate); requested before them it
+  // has the whole next tile to land.
   float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
   const __amdgpu_buffer_rsrc_t y_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
@@ -148,7 +153,6 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
 
   for (int mt = 0; mt < n_mt; ++mt) {
     const int buf = mt & 1;
-    if (mt + 1 < n_mt) copy_chunk(mt + 1, buf ^ 1);
     const int m0 = mt * 32;
     f32x16 acc;
 #pragma unroll
@@ -168,6 +172,8 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
     }
     // the next chunk has landed (and, the counter being one, the previous tile's stores are done)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (mt + 2 < n_mt) copy_chunk(mt + 2, buf);
     if (m0 + 32 <= M) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -180,7 +186,6 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), y_rsrc, vo, min(row, M - 1) * P * 4, 0);
       }
     }
-    __syncthreads();
   }
 }
 
