@@ -48,11 +48,14 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
                : "memory");
 }
 
-constexpr int B3_WAVES = 4;
-constexpr int B3_BN = 32 * B3_WAVES;   // pixels per workgroup
+// Waves per workgroup (32 pixels each): the waves of a workgroup share every weight chunk, so eight of them halve
+// the chunk traffic from L2 of four (LayerNorm GEMM 96 -> 510 at 65 536 pixels x 32 images: 1.41 -> 1.27 ms; sixteen:
+// no further gain, two: 1.77); grids too small to give every CU a few workgroups of eight use four.
+static int b3_waves(int P, int B) { return (long)((P + 255) / 256) * B >= 1024 ? 8 : 4; }
 
-template <int NS, bool LN>
+template <int NS, bool LN, int B3_WAVES>
 __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArgs a, const int tiles_n) {
+  constexpr int B3_BN = 32 * B3_WAVES;          // pixels per workgroup
   constexpr int K = NS * 16;
   constexpr int NG = NS * 2;                    // groups of eight k
   constexpr int CH = 3 * NG * 32;               // 16-byte slots of one weight chunk (plane, k group, row)
@@ -197,8 +200,9 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
 // 32 k x three planes, at most 18 KiB) in LDS.  No store happens inside the loop, so the loads' wait costs nothing
 // extra; bias, residual or gate, and the stores come once at the end.
 // ------------------------------------------------------------------------------------------------------------
-template <int NT, int EPI>
-__global__ __launch_bounds__(64 * B3_WAVES, 3) void gemm_k3_kernel(const GemmArgs a, const int tiles_n) {
+template <int NT, int EPI, int B3_WAVES>
+__global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_kernel(const GemmArgs a, const int tiles_n) {
+  constexpr int B3_BN = 32 * B3_WAVES;          // pixels per workgroup
   constexpr int R = NT * 32;                    // weight rows per k group
   constexpr int CH = 3 * 4 * R;                 // 16-byte slots of one chunk (plane, k group, row)
   constexpr int PIECES = CH / 64;
@@ -396,14 +400,15 @@ bool gemm_b3_covers(const GemmArgs& a, int loader) {
   return (long)a.M * a.P * 4 <= 0x7fffffffL && (long)a.K * a.P * 4 <= 0x7fffffffL;
 }
 
-void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
-  const int tiles_n = (a.P + B3_BN - 1) / B3_BN;
+template <int W>
+static void launch_gemm_b3_w(const GemmArgs& a, int loader, hipStream_t s) {
+  const int tiles_n = (a.P + 32 * W - 1) / (32 * W);
   const size_t smem = (size_t)((a.M + 31) / 32 * 32) * sizeof(float);
-  const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * B3_WAVES);
+  const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * W);
 #define JIRF_B3_CASE(NS)                                                                             \
   case NS:                                                                                           \
-    if (loader == LD_LN) hipLaunchKernelGGL((gemm_b3_kernel<NS, true>), grid, block, smem, s, a, tiles_n);   \
-    else hipLaunchKernelGGL((gemm_b3_kernel<NS, false>), grid, block, smem, s, a, tiles_n);           \
+    if (loader == LD_LN) hipLaunchKernelGGL((gemm_b3_kernel<NS, true, W>), grid, block, smem, s, a, tiles_n);   \
+    else hipLaunchKernelGGL((gemm_b3_kernel<NS, false, W>), grid, block, smem, s, a, tiles_n);           \
     break
   switch (a.K / 16) {
     JIRF_B3_CASE(2);
@@ -415,6 +420,10 @@ void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
 #undef JIRF_B3_CASE
   JIRF_HIP_CHECK(hipGetLastError());
 }
+void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
+  if (b3_waves(a.P, a.B) == 8) launch_gemm_b3_w<8>(a, loader, s);
+  else launch_gemm_b3_w<4>(a, loader, s);
+}
 
 // short outputs: M <= 96, the reduction a multiple of 32 after padding, plain store / residual / GELU gate
 bool gemm_k3_covers(const GemmArgs& a, int loader) {
@@ -422,25 +431,30 @@ bool gemm_k3_covers(const GemmArgs& a, int loader) {
   if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_GELU_MUL) return false;
   const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
   if (a.M > 96 || a.K < 96 || Kp % 32 != 0) return false;
-  if ((long)((a.P + B3_BN - 1) / B3_BN) * a.B < 512) return false;     // a grid that fills the chip
+  if ((long)((a.P + 127) / 128) * a.B < 512) return false;             // a grid that fills the chip
   return (long)a.M * a.P * 4 <= 0x7fffffffL && (long)a.K * a.P * 4 <= 0x7fffffffL;
 }
 
-void launch_gemm_k3(const GemmArgs& a, hipStream_t s) {
-  const int tiles_n = (a.P + B3_BN - 1) / B3_BN;
-  const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * B3_WAVES);
+template <int W>
+static void launch_gemm_k3_w(const GemmArgs& a, hipStream_t s) {
+  const int tiles_n = (a.P + 32 * W - 1) / (32 * W);
+  const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * W);
   const int NT = (a.M + 31) / 32;
 #define JIRF_K3_EPI(N)                                                                                              \
   do {                                                                                                              \
-    if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID>), grid, block, 0, s, a, tiles_n);        \
-    else if (a.epi == EP_GELU_MUL) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_GELU_MUL>), grid, block, 0, s, a, tiles_n); \
-    else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE>), grid, block, 0, s, a, tiles_n);                          \
+    if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W>), grid, block, 0, s, a, tiles_n);        \
+    else if (a.epi == EP_GELU_MUL) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_GELU_MUL, W>), grid, block, 0, s, a, tiles_n); \
+    else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W>), grid, block, 0, s, a, tiles_n);                          \
   } while (0)
   if (NT == 1) JIRF_K3_EPI(1);
   else if (NT == 2) JIRF_K3_EPI(2);
   else JIRF_K3_EPI(3);
 #undef JIRF_K3_EPI
   JIRF_HIP_CHECK(hipGetLastError());
+}
+void launch_gemm_k3(const GemmArgs& a, hipStream_t s) {
+  if (b3_waves(a.P, a.B) == 8) launch_gemm_k3_w<8>(a, s);
+  else launch_gemm_k3_w<4>(a, s);
 }
 
 }  // namespace jirf
