@@ -137,7 +137,7 @@ bool gemm_b3_covers(const GemmArgs& a, int loader);
 void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s);
 // ... and its form for short outputs (M <= 96), the reduction walked in chunks
 bool gemm_k3_covers(const GemmArgs& a, int loader);
-void launch_gemm_k3(const GemmArgs& a, hipStream_t s);
+void launch_gemm_k3(const GemmArgs& a, int loader, hipStream_t s);
 // host-side packers (return Kpad; out is resized to Kpad * Mpad)
 int pack_wt_1x1(const float* w, int M, int K, std::vector<float>& out, int* Mpad);
 int pack_wt_3x3(const float* w, int M, int Cin, std::vector<float>& out, int* Mpad);

@@ -1584,7 +1584,7 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
                   (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
   if (split_kind == 1) return launch_gemm_b3(a, loader, s);
   if (split_kind == 2) return launch_t3(a, loader, s);
-  if (split_kind == 3) return launch_gemm_k3(a, s);
+  if (split_kind == 3) return launch_gemm_k3(a, loader, s);
   if (!xs && try_launch_ws(a, loader, vec, s)) return;
   if (xs) {
     // 128-pixel tiles need K <= 128 (LDS) and enough of them: an underfilled grid does better with 64-pixel

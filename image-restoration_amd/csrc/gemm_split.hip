@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
 // 32 k x three planes, at most 18 KiB) in LDS.  No store happens inside the loop, so the loads' wait costs nothing
 // extra; bias, residual or gate, and the stores come once at the end.
 // ------------------------------------------------------------------------------------------------------------
-template <int NT, int EPI, int B3_WAVES>
+template <int NT, int EPI, int B3_WAVES, bool CONV>
 __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_kernel(const GemmArgs a, const int tiles_n) {
   constexpr int B3_BN = 32 * B3_WAVES;          // pixels per workgroup
   constexpr int R = NT * 32;                    // weight rows per k group
@@ -218,19 +218,24 @@ __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_
 
   const u32x4* __restrict__ W3 = reinterpret_cast<const u32x4*>(a.wt3);
   const int plane16 = (int)(a.wt3_plane / 8);
-  const u32x4* w_src[PW];
+  const int ngroups = (K + GEMM_KPAD - 1) / GEMM_KPAD * 2;     // k groups of eight in a plane
+  int w_off[PW], w_g[PW];
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
     const int q = min((wave + i * B3_WAVES) * 64 + lane, CH - 1);
-    const int pl = q / (4 * R), g = (q / R) & 3, m = q % R;
-    w_src[i] = W3 + pl * plane16 + g * a.Mpad + min(m, a.Mpad - 1);
+    const int pl = q / (4 * R), m = q % R;
+    w_g[i] = (q / R) & 3;
+    w_off[i] = pl * plane16 + min(m, a.Mpad - 1);
   }
   const unsigned abuf0 = (unsigned)(uintptr_t)&Abuf[0][0];
+  // (a reduction that is no multiple of 32 ends in half a chunk: its missing k groups re-read the last one, and meet
+  //  zeros on the activation side)
   auto copy_chunk = [&](int kc, int buf) {
 #pragma unroll
     for (int i = 0; i < PW; ++i)
       if (PIECES % B3_WAVES == 0 || wave + i * B3_WAVES < PIECES)   // wave-uniform
-        dma16(w_src[i] + (long)kc * 4 * a.Mpad, abuf0 + (unsigned)(buf * CH + (wave + i * B3_WAVES) * 64) * 16u);
+        dma16(W3 + w_off[i] + (long)min(4 * kc + w_g[i], ngroups - 1) * a.Mpad,
+              abuf0 + (unsigned)(buf * CH + (wave + i * B3_WAVES) * 64) * 16u);
   };
 
   const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
@@ -239,8 +244,36 @@ __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_
   const int pix = n0 + wave * 32 + l31;
   const int OOB = 0x7fffffff;
   const int x_voff = (8 * half * P + min(pix, P - 1)) * 4;
+  // implicit k x k convolution (k = tap * Cin + c, Cin % 16 == 0): the sixteen k of a step share one tap, a scalar;
+  // the lane's input coordinate moves with it, the plane advance is the scalar offset, and a tap in the zero padding
+  // is an out-of-range offset
+  int cv_y = 0, cv_x = 0;
+  __amdgpu_buffer_rsrc_t cv_rsrc = x_rsrc;
+  if constexpr (CONV) {
+    const int pc = min(pix, P - 1), yy = pc / a.W;
+    cv_y = yy * a.stride - a.pad;
+    cv_x = (pc - yy * a.W) * a.stride - a.pad;
+    cv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0,
+                                                (int)min((long)a.Cin * a.Hin * a.Win * 4, 0x7fffffffL), 0x00020000);
+  }
   float raw[2][8];
   auto fetch = [&](int kc) {   // channels 32 kc + 16 s + 8 half + i; rows past K read as zero (out-of-range offset)
+    if constexpr (CONV) {
+      const int plane_b = a.Hin * a.Win * 4;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int k0 = 32 * kc + 16 * s;
+        const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+        const int ky = tap / a.ks, kx = tap - ky * a.ks;
+        const int iy = cv_y + ky, ix = cv_x + kx;
+        const bool ok = k0 < K && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int vo = ok ? (iy * a.Win + ix) * 4 + 8 * half * plane_b : OOB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          raw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cv_rsrc, vo, min(c0 + i, a.Cin - 1) * plane_b, 0));
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -306,7 +339,13 @@ __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_
   float* __restrict__ yb = a.y.p + (long)b * a.y.bs;
   const __amdgpu_buffer_rsrc_t y_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
-  const int pv = pix < P ? (4 * half * P + pix) * 4 : OOB;
+  int pv = pix < P ? (4 * half * P + pix) * 4 : OOB;
+  if constexpr (EPI == EP_UNSHUFFLE) {
+    // pixel-unshuffle(2): output channel 4 row + 2 (y & 1) + (x & 1) at (y >> 1, x >> 1); the row part of the address
+    // is the same scalar as for a plain store (4 row planes of P / 4 = row * P)
+    const int py = pix / a.W, px = pix - py * a.W;
+    pv = pix < P ? ((2 * (py & 1) + (px & 1) + 16 * half) * (P >> 2) + (py >> 1) * (a.W >> 1) + (px >> 1)) * 4 : OOB;
+  }
   __amdgpu_buffer_rsrc_t r_rsrc = y_rsrc;
   if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL)
     r_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.r.p + (long)b * a.r.bs, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
@@ -425,26 +464,35 @@ void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
   else launch_gemm_b3_w<4>(a, loader, s);
 }
 
-// short outputs: M <= 96, the reduction a multiple of 32 after padding, plain store / residual / GELU gate
+// short outputs (M <= 96): 1x1 with plain store / residual / GELU gate, or a dense k x k convolution (Cin % 16 == 0,
+// more outputs than the few-output kernel takes) with plain store / residual / pixel-unshuffle
 bool gemm_k3_covers(const GemmArgs& a, int loader) {
-  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || loader != LD_PLAIN || a.k_split > 0) return false;
-  if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_GELU_MUL) return false;
-  const int Kp = (a.K + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD;
-  if (a.M > 96 || a.K < 96 || Kp % 32 != 0) return false;
+  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || a.k_split > 0 || a.M > 96) return false;
   if ((long)((a.P + 127) / 128) * a.B < 512) return false;             // a grid that fills the chip
-  return (long)a.M * a.P * 4 <= 0x7fffffffL && (long)a.K * a.P * 4 <= 0x7fffffffL;
+  if ((long)a.M * a.P * 4 > 0x7fffffffL) return false;
+  if (loader == LD_CONV3) {
+    if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_UNSHUFFLE) return false;
+    return a.M >= 17 && a.Cin % 16 == 0 && (long)a.Cin * a.Hin * a.Win * 4 <= 0x7fffffffL;
+  }
+  if (loader != LD_PLAIN) return false;
+  if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_GELU_MUL) return false;
+  return a.K >= 96 && (long)a.K * a.P * 4 <= 0x7fffffffL;
 }
 
 template <int W>
-static void launch_gemm_k3_w(const GemmArgs& a, hipStream_t s) {
+static void launch_gemm_k3_w(const GemmArgs& a, int loader, hipStream_t s) {
   const int tiles_n = (a.P + 32 * W - 1) / (32 * W);
   const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * W);
   const int NT = (a.M + 31) / 32;
 #define JIRF_K3_EPI(N)                                                                                              \
   do {                                                                                                              \
-    if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W>), grid, block, 0, s, a, tiles_n);        \
-    else if (a.epi == EP_GELU_MUL) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_GELU_MUL, W>), grid, block, 0, s, a, tiles_n); \
-    else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W>), grid, block, 0, s, a, tiles_n);                          \
+    if (loader == LD_CONV3) {                                                                                       \
+      if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W, true>), grid, block, 0, s, a, tiles_n);   \
+      else if (a.epi == EP_UNSHUFFLE) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_UNSHUFFLE, W, true>), grid, block, 0, s, a, tiles_n); \
+      else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W, true>), grid, block, 0, s, a, tiles_n);                \
+    } else if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W, false>), grid, block, 0, s, a, tiles_n); \
+    else if (a.epi == EP_GELU_MUL) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_GELU_MUL, W, false>), grid, block, 0, s, a, tiles_n); \
+    else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W, false>), grid, block, 0, s, a, tiles_n);                 \
   } while (0)
   if (NT == 1) JIRF_K3_EPI(1);
   else if (NT == 2) JIRF_K3_EPI(2);
@@ -452,9 +500,9 @@ static void launch_gemm_k3_w(const GemmArgs& a, hipStream_t s) {
 #undef JIRF_K3_EPI
   JIRF_HIP_CHECK(hipGetLastError());
 }
-void launch_gemm_k3(const GemmArgs& a, hipStream_t s) {
-  if (b3_waves(a.P, a.B) == 8) launch_gemm_k3_w<8>(a, s);
-  else launch_gemm_k3_w<4>(a, s);
+void launch_gemm_k3(const GemmArgs& a, int loader, hipStream_t s) {
+  if (b3_waves(a.P, a.B) == 8) launch_gemm_k3_w<8>(a, loader, s);
+  else launch_gemm_k3_w<4>(a, loader, s);
 }
 
 }  // namespace jirf

@@ -214,7 +214,7 @@ PackedW pack_upload_conv(WeightPool& pool, const float* w, const float* bias, in
   out.wt = pool.upload(packed);
   out.bias = bias ? pool.upload(bias, M) : nullptr;
   out.M = M; out.K = ks * ks * Cin; out.Cin = Cin;
-  if (gemm_split_bf16_enabled() && Cin % 8 == 0 && M >= 96) {   // what the split K-loop kernel's conv loader takes
+  if (gemm_split_bf16_enabled() && Cin % 8 == 0 && M >= 17) {   // what the split kernels' conv loaders take
     std::vector<uint16_t> planes;
     out.wt3_plane = (long)pack_split3_kmajor(packed, kp, out.Mpad, planes);
     planes.resize((planes.size() + 1) / 2 * 2, 0);

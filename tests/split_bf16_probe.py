@@ -55,6 +55,18 @@ def main():
     call("jirf_op_conv3x3", ptr(xd), hptr(w), hptr(bias), None, ptr(y), B, Cin, Cout, H, W, 1, stream())
     unsh = torch.nn.functional.pixel_unshuffle(torch.from_numpy(ref), 2).numpy()
     out["conv3x3_unshuffle"] = float(np.abs(y.cpu().numpy().reshape(unsh.shape) - unsh).max())
+    # ... and with few outputs (the chunked form): first down-sampling convolution of HINT, 48 -> 24 + pixel-unshuffle
+    B, Cin, Cout, H, W = 2, 48, 24, 256, 256
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * (9 * Cin) ** -0.5).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, padding=1).numpy()
+    xd = dev(x)
+    y = torch.empty(B, Cout, H, W, device="cuda")
+    call("jirf_op_conv3x3", ptr(xd), hptr(w), None, None, ptr(y), B, Cin, Cout, H, W, 0, stream())
+    out["conv3x3_fewrows_plain"] = float(np.abs(y.cpu().numpy() - ref).max())
+    call("jirf_op_conv3x3", ptr(xd), hptr(w), None, None, ptr(y), B, Cin, Cout, H, W, 1, stream())
+    unsh = torch.nn.functional.pixel_unshuffle(torch.from_numpy(ref), 2).numpy()
+    out["conv3x3_fewrows_unshuffle"] = float(np.abs(y.cpu().numpy().reshape(unsh.shape) - unsh).max())
     print(json.dumps(out))
 
 
