@@ -84,6 +84,7 @@ struct GemmArgs {
   long wt_bs;            // batch stride of wt (0: shared)
   const uint16_t* wt3 = nullptr;  // optional: the same weights split into three bf16 planes (see pack_wt_split3)
   long wt3_plane = 0;             // elements per plane
+  long wt3_bs = 0;                // batch stride of the planes in elements (0: shared)
   const float* bias;     // [M] or null
   long bias_bs = 0;      // > 0: one bias vector per image, bias + b * bias_bs
   TV x;                  // input activation
@@ -135,6 +136,8 @@ size_t pack_split3_kmajor(const std::vector<float>& packed, int Kp, int Mpad, st
 // split-bf16 GEMM with the pixel operand in registers (gemm_split.hip): whether it serves this launch, and the launch
 bool gemm_b3_covers(const GemmArgs& a, int loader);
 void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s);
+// per-image K-major fp32 matrices [B][Kp][Mpad] -> three bf16 planes each, [B][3][Kp / 8][Mpad][8] (on the device)
+void launch_split_planes(const float* w, uint16_t* planes, int B, int Kp, int Mpad, hipStream_t s);
 // ... and its form for short outputs (M <= 96), the reduction walked in chunks
 bool gemm_k3_covers(const GemmArgs& a, int loader);
 void launch_gemm_k3(const GemmArgs& a, int loader, hipStream_t s);
@@ -227,6 +230,7 @@ struct HintAttnScratch {   // device scratch, carved by hint_attn_scratch_carve
   float* rq;           // [B][C] reciprocal L2 norms of the q rows
   float* rk;           // [B][C]
   float* att_t;        // [B][Kpad][Mpad] block-diagonal attention, transposed (GEMM weight layout)
+  uint16_t* att3;      // [B][3][Kpad / 8][Mpad][8] att_t as three bf16 planes (filled when the split GEMMs are on)
   float* att_nat;      // [B][C][C] block-diagonal attention, natural orientation
   float* pooled;       // [G][C][C] carried cache pooled to this block's C
   float* pooled_g;     // [G][sum c_g^2] the same pooled once more to every group's c x c

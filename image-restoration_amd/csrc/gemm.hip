@@ -1564,7 +1564,7 @@ void launch_gemm(const GemmArgs& a_in, int loader, hipStream_t s) {
   const bool xs_shape = xs_enabled() && loader != LD_CONV3 && a.K <= 256 &&
                         (loader == LD_LN || (a.K <= 128 && (a.M >= 2 * a.K || loader == LD_GATHER)));
   const int split_kind = tile_forced_early ? 0 : (xs_shape && gemm_b3_covers(a, loader)) ? 1 : t3_covers(a, loader) ? 2
-                         : (!xs_shape && gemm_k3_covers(a, loader)) ? 3 : 0;
+                         : ((!xs_shape || loader == LD_GATHER) && gemm_k3_covers(a, loader)) ? 3 : 0;
   Scope sc(intern_label("%s%s M%d K%d P%d", name, split_kind ? "_bf16x3" : "", a.M, a.K, a.P), flops, bytes, s);
 
   // the RGB output convolutions: a handful of output rows would idle the matrix cores

@@ -200,8 +200,9 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
 // 32 k x three planes, at most 18 KiB) in LDS.  No store happens inside the loop, so the loads' wait costs nothing
 // extra; bias, residual or gate, and the stores come once at the end.
 // ------------------------------------------------------------------------------------------------------------
-template <int NT, int EPI, int B3_WAVES, bool CONV>
+template <int NT, int EPI, int B3_WAVES, int LOADER>
 __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_kernel(const GemmArgs a, const int tiles_n) {
+  constexpr bool CONV = LOADER == LD_CONV3;
   constexpr int B3_BN = 32 * B3_WAVES;          // pixels per workgroup
   constexpr int R = NT * 32;                    // weight rows per k group
   constexpr int CH = 3 * 4 * R;                 // 16-byte slots of one chunk (plane, k group, row)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_
   const int P = a.P, M = a.M, K = a.K;
   const int nch = (K + 31) >> 5;
 
-  const u32x4* __restrict__ W3 = reinterpret_cast<const u32x4*>(a.wt3);
+  const u32x4* __restrict__ W3 = reinterpret_cast<const u32x4*>(a.wt3) + (long)b * (a.wt3_bs / 8);
   const int plane16 = (int)(a.wt3_plane / 8);
   const int ngroups = (K + GEMM_KPAD - 1) / GEMM_KPAD * 2;     // k groups of eight in a plane
   int w_off[PW], w_g[PW];
@@ -272,6 +273,20 @@ __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_
         for (int i = 0; i < 8; ++i)
           raw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cv_rsrc, vo, min(c0 + i, a.Cin - 1) * plane_b, 0));
       }
+      return;
+    }
+    if constexpr (LOADER == LD_GATHER) {   // row kidx[k] instead of row k (the same order for every image of a group)
+      const int* __restrict__ kx = a.kidx + (long)(b / a.imgs_per_group) * K;
+      const int pc4 = min(pix, P - 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = 32 * kc + 16 * s + i;
+          const int r0 = kx[min(k, K - 1)], r1 = kx[min(k + 8, K - 1)];
+          const int vo = k + 8 * half < K ? ((half ? r1 : r0) * P + pc4) * 4 : OOB;
+          raw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, vo, 0, 0));
+        }
       return;
     }
 #pragma unroll
@@ -349,6 +364,45 @@ __global__ __launch_bounds__(64 * B3_WAVES, B3_WAVES == 8 ? 4 : 3) void gemm_k3_
   __amdgpu_buffer_rsrc_t r_rsrc = y_rsrc;
   if constexpr (EPI == EP_RESID || EPI == EP_GELU_MUL)
     r_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.r.p + (long)b * a.r.bs, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
+  if constexpr (EPI == EP_AV_INTRA) {
+    // y = acc; y2 = acc + q[src] * rq[src] + k[src] * rk[src] with src = the order's entry for the output row
+    const int* __restrict__ perm = a.kidx + (long)(b / a.imgs_per_group) * M;
+    const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.q.p + (long)b * a.q.bs, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.k.p + (long)b * a.k.bs, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.y2.p + (long)b * a.y2.bs, 0, (int)min((long)M * P * 4, 0x7fffffffL), 0x00020000);
+    const float* __restrict__ rq = a.rq + (long)b * M;
+    const float* __restrict__ rk = a.rk + (long)b * M;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int m0 = t * 32;
+      if (m0 >= M) continue;
+      float qv[16], kv[16], sq[16], sk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2);
+        const int s0 = perm[min(row, M - 1)], s1 = perm[min(row + 4, M - 1)];
+        const int src = half ? s1 : s0;
+        const int vo = row + 4 * half < M && pix < P ? (src * P + pix) * 4 : OOB;
+        qv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(q_rsrc, vo, 0, 0));
+        kv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(k_rsrc, vo, 0, 0));
+        sq[r] = half ? rq[s1] : rq[s0];
+        sk[r] = half ? rk[s1] : rk[s0];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2);
+        const int vo = row + 4 * half < M ? pv : OOB;
+        const float v = acc[t][r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, vo, min(row, M - 1) * P * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v + qv[r] * sq[r] + kv[r] * sk[r]), y2_rsrc, vo,
+                                              min(row, M - 1) * P * 4, 0);
+      }
+    }
+    return;
+  }
   const float* __restrict__ bias = a.bias ? a.bias + (long)b * a.bias_bs : nullptr;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -464,16 +518,47 @@ void launch_gemm_b3(const GemmArgs& a, int loader, hipStream_t s) {
   else launch_gemm_b3_w<4>(a, loader, s);
 }
 
+// per-image fp32 matrices -> bf16 planes: thread (image, k group, column) reads its eight k and writes three 16-byte words
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, u32x4* __restrict__ planes,
+                                                           const int B, const int Kp, const int Mpad) {
+  const long n = (long)B * (Kp / 8) * Mpad;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int m = (int)(e % Mpad);
+  const long bg = e / Mpad;
+  const int g = (int)(bg % (Kp / 8)), b = (int)(bg / (Kp / 8));
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = w[((long)b * Kp + 8 * g + i) * Mpad + m];
+  bf16x8 h, mi, l;
+  split8(v, h, mi, l);
+  const long plane16 = (long)(Kp / 8) * Mpad;
+  u32x4* __restrict__ dst = planes + (long)b * 3 * plane16 + (long)g * Mpad + m;
+  dst[0] = __builtin_bit_cast(u32x4, h);
+  dst[plane16] = __builtin_bit_cast(u32x4, mi);
+  dst[2 * plane16] = __builtin_bit_cast(u32x4, l);
+}
+void launch_split_planes(const float* w, uint16_t* planes, int B, int Kp, int Mpad, hipStream_t s) {
+  const long n = (long)B * (Kp / 8) * Mpad;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w,
+                     reinterpret_cast<u32x4*>(planes), B, Kp, Mpad);
+  JIRF_HIP_CHECK(hipGetLastError());
+}
+
 // short outputs (M <= 96): 1x1 with plain store / residual / GELU gate, or a dense k x k convolution (Cin % 16 == 0,
 // more outputs than the few-output kernel takes) with plain store / residual / pixel-unshuffle
 bool gemm_k3_covers(const GemmArgs& a, int loader) {
-  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || a.k_split > 0 || a.M > 96) return false;
+  if (!gemm_split_bf16_enabled() || !a.wt3 || a.k_split > 0 || a.M > 96) return false;
+  if ((a.wt_bs != 0) != (a.wt3_bs != 0)) return false;                 // per-image weights need per-image planes
+  if (loader != LD_GATHER && a.wt_bs != 0) return false;
   if ((long)((a.P + 127) / 128) * a.B < 512) return false;             // a grid that fills the chip
   if ((long)a.M * a.P * 4 > 0x7fffffffL) return false;
   if (loader == LD_CONV3) {
     if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_UNSHUFFLE) return false;
     return a.M >= 17 && a.Cin % 16 == 0 && (long)a.Cin * a.Hin * a.Win * 4 <= 0x7fffffffL;
   }
+  if (loader == LD_GATHER)   // attention * V with its fused tail: square, a channel order for rows and outputs
+    return a.epi == EP_AV_INTRA && a.kidx && a.K == a.M && a.K >= 32 && !a.bias && (long)a.K * a.P * 4 <= 0x7fffffffL;
   if (loader != LD_PLAIN) return false;
   if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_GELU_MUL) return false;
   return a.K >= 96 && (long)a.K * a.P * 4 <= 0x7fffffffL;
@@ -486,13 +571,15 @@ static void launch_gemm_k3_w(const GemmArgs& a, int loader, hipStream_t s) {
   const int NT = (a.M + 31) / 32;
 #define JIRF_K3_EPI(N)                                                                                              \
   do {                                                                                                              \
-    if (loader == LD_CONV3) {                                                                                       \
-      if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W, true>), grid, block, 0, s, a, tiles_n);   \
-      else if (a.epi == EP_UNSHUFFLE) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_UNSHUFFLE, W, true>), grid, block, 0, s, a, tiles_n); \
-      else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W, true>), grid, block, 0, s, a, tiles_n);                \
-    } else if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W, false>), grid, block, 0, s, a, tiles_n); \
-    else if (a.epi == EP_GELU_MUL) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_GELU_MUL, W, false>), grid, block, 0, s, a, tiles_n); \
-    else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W, false>), grid, block, 0, s, a, tiles_n);                 \
+    if (loader == LD_GATHER) {                                                                                      \
+      hipLaunchKernelGGL((gemm_k3_kernel<N, EP_AV_INTRA, W, LD_GATHER>), grid, block, 0, s, a, tiles_n);            \
+    } else if (loader == LD_CONV3) {                                                                                \
+      if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W, LD_CONV3>), grid, block, 0, s, a, tiles_n);   \
+      else if (a.epi == EP_UNSHUFFLE) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_UNSHUFFLE, W, LD_CONV3>), grid, block, 0, s, a, tiles_n); \
+      else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W, LD_CONV3>), grid, block, 0, s, a, tiles_n);            \
+    } else if (a.epi == EP_RESID) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_RESID, W, LD_PLAIN>), grid, block, 0, s, a, tiles_n); \
+    else if (a.epi == EP_GELU_MUL) hipLaunchKernelGGL((gemm_k3_kernel<N, EP_GELU_MUL, W, LD_PLAIN>), grid, block, 0, s, a, tiles_n); \
+    else hipLaunchKernelGGL((gemm_k3_kernel<N, EP_STORE, W, LD_PLAIN>), grid, block, 0, s, a, tiles_n);              \
   } while (0)
   if (NT == 1) JIRF_K3_EPI(1);
   else if (NT == 2) JIRF_K3_EPI(2);

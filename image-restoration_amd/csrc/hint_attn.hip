@@ -1102,6 +1102,7 @@ size_t hint_attn_scratch_carve(const HintAttnShape& sh, void* base, HintAttnScra
   o->rq = static_cast<float*>(take(B * C * 4));
   o->rk = static_cast<float*>(take(B * C * 4));
   o->att_t = static_cast<float*>(take(B * kpad * mpad * 4));
+  o->att3 = static_cast<uint16_t*>(take(B * 3 * kpad * mpad * 2));
   o->att_nat = static_cast<float*>(take(B * C * C * 4));
   o->pooled = static_cast<float*>(take(G * C * C * 4));
   o->pooled_g = static_cast<float*>(take(G * C * C * 4));  // sum of c_g^2 <= C^2

@@ -481,6 +481,14 @@ class HintNet final : public Net {
       g.Mpad = (C + GEMM_MPAD - 1) / GEMM_MPAD * GEMM_MPAD;
       g.wt = sc.att_t;
       g.wt_bs = (long)((C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD) * g.Mpad;
+      // The split kernel for short outputs can take this product too (per-image planes made on the device), but
+      // its gathered rows cost a vector multiply-add per load and it runs at 3.1 TB/s against 4.7 for the fp32
+      // kernel below (10.6 against 6.9 ms per step at 256 x 256, 32 images): opt-in only, JIRF_ATTN_V_SPLIT=1.
+      static const bool attn_v_split = std::getenv("JIRF_ATTN_V_SPLIT") && std::atoi(std::getenv("JIRF_ATTN_V_SPLIT")) != 0;
+      if (attn_v_split && gemm_split_bf16_enabled() && C <= 96) {
+        launch_split_planes(sc.att_t, sc.att3, B, (C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD, g.Mpad, s);
+        g.wt3 = sc.att3; g.wt3_plane = g.wt_bs; g.wt3_bs = 3 * g.wt_bs;
+      }
       g.x = tv_chan(t2, 2 * C, P);
       g.kidx = perm; g.imgs_per_group = B / sh.G;
       g.y = tv_chan(t1, C, P); g.y2 = tv_chan(t1, 2 * C, P);

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"JIRF_GEMM_TILE": "2"},                                  # ... 64 x 128 (the default only picks it at large batches)
     {"JIRF_GEMM_TILE": "1"},                                  # ... 128 x 128
     {"JIRF_GEMM_TILE": "0"},                                  # ... 96 x 128
+    {"JIRF_ATTN_V_SPLIT": "1"},                               # attention * V on the split kernel for short outputs
     {"JIRF_GEMM_SPLIT_BF16": "0"},                            # every GEMM on the fp32 matrix instruction (split-bf16 forms off)
 ])
 def test_golden_cases_with_switches(switches):
