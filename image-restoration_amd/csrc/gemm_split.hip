@@ -53,7 +53,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 // no further gain, two: 1.77); grids too small to give every CU a few workgroups of eight use four.
 static int b3_waves(int P, int B) { return (long)((P + 255) / 256) * B >= 1024 ? 8 : 4; }
 
-template <int NS, bool LN, int B3_WAVES>
+template <int NS, bool LN, int B3_WAVES, bool GELU>
 __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArgs a, const int tiles_n) {
   constexpr int B3_BN = 32 * B3_WAVES;          // pixels per workgroup
   constexpr int K = NS * 16;
@@ -94,16 +94,21 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
 
   // ---- the wave's 32 pixels: load, normalise, split ---------------------------------------------------
   const float* __restrict__ xb = a.x.p + (long)b * a.x.bs;
-  const __amdgpu_buffer_rsrc_t x_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)min((long)K * P * 4, 0x7fffffffL), 0x00020000);
   const int pix = n0 + wave * 32 + l31;
   const int x_voff = (8 * half * P + min(pix, P - 1)) * 4;
+  // (plain loads may take their first k_split rows, a multiple of 8, from a second tensor of the same arena - a
+  //  concatenation never made: the same descriptor, those lanes' offsets moved by the distance between the two)
+  const long x2_delta = !LN && a.k_split > 0 ? (long)((a.x2.p + (long)b * a.x2.bs) - xb) * 4 : 0;
+  const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)min((long)K * P * 4 + x2_delta, 0x7fffffffL), 0x00020000);
   float raw[NS][8];
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < NS; ++s) {
+    const int vo = x_voff + (16 * s + 8 * half < a.k_split && !LN ? (int)x2_delta : 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      raw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_voff, (16 * s + i) * P * 4, 0));
+      raw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xs_rsrc, vo, (16 * s + i) * P * 4, 0));
+  }
 
   {   // the output bias waits in LDS (rows past M as zeros)
     const float* __restrict__ bsrc = a.bias ? a.bias + (long)b * a.bias_bs : nullptr;
@@ -180,13 +185,15 @@ __global__ __launch_bounds__(64 * B3_WAVES, 4) void gemm_b3_kernel(const GemmArg
     if (m0 + 32 <= M) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), y_rsrc, y_voff, (m0 + (r & 3) + 8 * (r >> 2)) * P * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(GELU ? gelu_fast(acc[r]) : acc[r]), y_rsrc, y_voff,
+                                              (m0 + (r & 3) + 8 * (r >> 2)) * P * 4, 0);
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + (r & 3) + 8 * (r >> 2);
         const int vo = row + 4 * half < M ? y_voff : OOB;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), y_rsrc, vo, min(row, M - 1) * P * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(GELU ? gelu_fast(acc[r]) : acc[r]), y_rsrc, vo,
+                                              min(row, M - 1) * P * 4, 0);
       }
     }
   }
@@ -484,10 +491,15 @@ size_t pack_split3_kmajor(const std::vector<float>& packed, int Kp, int Mpad, st
   return plane;
 }
 
-// LayerNorm or plain 1x1 GEMM with a plain store; false when the shape is not one this kernel is built for.
+// LayerNorm or plain 1x1 GEMM with a plain store (plain: also GELU, and a second source for the first rows); false when the shape is not one this kernel is built for.
 bool gemm_b3_covers(const GemmArgs& a, int loader) {
-  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0 || a.epi != EP_STORE || a.k_split > 0) return false;
+  if (!gemm_split_bf16_enabled() || !a.wt3 || a.wt_bs != 0) return false;
   if (loader != LD_LN && loader != LD_PLAIN) return false;
+  if (a.epi != EP_STORE && !(loader == LD_PLAIN && a.epi == EP_GELU)) return false;
+  if (a.k_split > 0) {   // a second source: same arena, behind the first, within a descriptor's reach
+    if (loader != LD_PLAIN || a.k_split % 8 != 0 || a.x.bs != a.x2.bs || a.x2.p < a.x.p) return false;
+    if ((long)(a.x2.p - a.x.p) * 4 + (long)a.K * a.P * 4 > 0x7fffffffL) return false;
+  }
   if (!gemm_split_bf16_covers(a.K)) return false;
   if (loader == LD_LN && a.lnw) return false;   // the affine part must be folded into the weights
   return (long)a.M * a.P * 4 <= 0x7fffffffL && (long)a.K * a.P * 4 <= 0x7fffffffL;
@@ -500,8 +512,9 @@ static void launch_gemm_b3_w(const GemmArgs& a, int loader, hipStream_t s) {
   const dim3 grid((unsigned)(tiles_n * a.B)), block(64 * W);
 #define JIRF_B3_CASE(NS)                                                                             \
   case NS:                                                                                           \
-    if (loader == LD_LN) hipLaunchKernelGGL((gemm_b3_kernel<NS, true, W>), grid, block, smem, s, a, tiles_n);   \
-    else hipLaunchKernelGGL((gemm_b3_kernel<NS, false, W>), grid, block, smem, s, a, tiles_n);           \
+    if (loader == LD_LN) hipLaunchKernelGGL((gemm_b3_kernel<NS, true, W, false>), grid, block, smem, s, a, tiles_n);   \
+    else if (a.epi == EP_GELU) hipLaunchKernelGGL((gemm_b3_kernel<NS, false, W, true>), grid, block, smem, s, a, tiles_n); \
+    else hipLaunchKernelGGL((gemm_b3_kernel<NS, false, W, false>), grid, block, smem, s, a, tiles_n);    \
     break
   switch (a.K / 16) {
     JIRF_B3_CASE(2);

@@ -351,6 +351,7 @@ class AstNet final : public Net {
       GemmArgs g{};
     g.splitk_ws = splitk_; g.splitk_floats = SPLITK_WS_FLOATS;
       g.B = B; g.M = 2 * h; g.K = C; g.P = P; g.Mpad = bl.lin1.Mpad; g.wt = bl.lin1.wt; g.bias = bl.lin1.bias;
+      g.wt3 = bl.lin1.wt3; g.wt3_plane = bl.lin1.wt3_plane;
       g.x = tv_chan(t2, 0, P); g.x2 = tv_chan(t2, C, P); g.k_split = C / 4;
       g.y = t1; g.epi = EP_GELU; g.imgs_per_group = 1;
       launch_gemm(g, LD_PLAIN, s);
