@@ -255,6 +255,7 @@ struct HeadAttnScratch {
   float* rq;       // [B][C]
   float* rk;       // [B][C]
   float* att_t;    // [B][Kpad][Mpad] block-diagonal attention, transposed (GEMM weight layout)
+  uint16_t* att3;  // [B][3][Kpad / 8][Mpad][8] the same as three bf16 planes (filled by the caller when it wants them)
 };
 int head_attn_splits(int B, int C, int P);
 size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, HeadAttnScratch* out);

@@ -500,7 +500,7 @@ bool gemm_b3_covers(const GemmArgs& a, int loader) {
     if (loader != LD_PLAIN || a.k_split % 8 != 0 || a.x.bs != a.x2.bs || a.x2.p < a.x.p) return false;
     if ((long)(a.x2.p - a.x.p) * 4 + (long)a.K * a.P * 4 > 0x7fffffffL) return false;
   }
-  if (!gemm_split_bf16_covers(a.K)) return false;
+  if (!gemm_split_bf16_covers(a.K) || a.M > 4096) return false;   // (the output bias of all rows waits in LDS)
   if (loader == LD_LN && a.lnw) return false;   // the affine part must be folded into the weights
   return (long)a.M * a.P * 4 <= 0x7fffffffL && (long)a.K * a.P * 4 <= 0x7fffffffL;
 }
@@ -563,7 +563,7 @@ void launch_split_planes(const float* w, uint16_t* planes, int B, int Kp, int Mp
 bool gemm_k3_covers(const GemmArgs& a, int loader) {
   if (!gemm_split_bf16_enabled() || !a.wt3 || a.k_split > 0 || a.M > 96) return false;
   if ((a.wt_bs != 0) != (a.wt3_bs != 0)) return false;                 // per-image weights need per-image planes
-  if (loader != LD_GATHER && a.wt_bs != 0) return false;
+  if (a.wt_bs != 0 && loader != LD_GATHER && !(loader == LD_PLAIN && a.epi == EP_STORE)) return false;
   if ((long)((a.P + 127) / 128) * a.B < 512) return false;             // a grid that fills the chip
   if ((long)a.M * a.P * 4 > 0x7fffffffL) return false;
   if (loader == LD_CONV3) {
@@ -574,7 +574,7 @@ bool gemm_k3_covers(const GemmArgs& a, int loader) {
     return a.epi == EP_AV_INTRA && a.kidx && a.K == a.M && a.K >= 32 && !a.bias && (long)a.K * a.P * 4 <= 0x7fffffffL;
   if (loader != LD_PLAIN) return false;
   if (a.epi != EP_STORE && a.epi != EP_RESID && a.epi != EP_GELU_MUL) return false;
-  return a.K >= 96 && (long)a.K * a.P * 4 <= 0x7fffffffL;
+  return a.K >= (a.wt_bs != 0 ? 32 : 96) && (long)a.K * a.P * 4 <= 0x7fffffffL;
 }
 
 template <int W>

@@ -1334,6 +1334,7 @@ size_t head_attn_scratch_carve(int B, int C, int P, int splits, void* base, Head
   o->rq = static_cast<float*>(take((size_t)B * C * 4));
   o->rk = static_cast<float*>(take((size_t)B * C * 4));
   o->att_t = static_cast<float*>(take((size_t)B * kpad * mpad * 4));
+  o->att3 = static_cast<uint16_t*>(take((size_t)B * 3 * kpad * mpad * 2));
   return off;
 }
 

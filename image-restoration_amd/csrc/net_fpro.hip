@@ -436,6 +436,11 @@ class FproNet final : public Net {
       g.wt_bs = (long)((C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD) * g.Mpad;
       g.x = tv_chan(t2, 2 * C, P); g.y = tv_chan(t1, 0, P);
       g.epi = EP_STORE; g.imgs_per_group = 1;
+      if (gemm_split_bf16_enabled() && C <= 96 && (long)((P + 127) / 128) * B >= 512) {
+        // the split kernel for short outputs takes per-image weights as per-image planes, made here on the device
+        launch_split_planes(sc.att_t, sc.att3, B, (C + GEMM_KPAD - 1) / GEMM_KPAD * GEMM_KPAD, g.Mpad, s);
+        g.wt3 = sc.att3; g.wt3_plane = g.wt_bs; g.wt3_bs = 3 * g.wt_bs;
+      }
       launch_gemm(g, LD_PLAIN, s);
       gemm(bl.proj, tv_chan(t1, 0, P), x, B, P, EP_RESID, x, s);
     }
