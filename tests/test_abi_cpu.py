@@ -30,6 +30,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.jirf_abi_version() == 1
 
 
+def test_gemm_arithmetic_switch_returns_the_previous_setting():
+    """No GPU needed: the switch is host state.  The split-bf16 forms are on unless the environment says otherwise."""
+    lib = jirf_hip.lib()
+    default = 0 if os.environ.get("JIRF_GEMM_SPLIT_BF16", "1") in ("0", "") else 1
+    before = lib.jirf_set_gemm_split_bf16(0)
+    try:
+        assert before == default
+        assert lib.jirf_set_gemm_split_bf16(1) == 0
+        assert lib.jirf_set_gemm_split_bf16(5) == 1      # any non-zero value means on
+        assert lib.jirf_set_gemm_split_bf16(1) == 1
+    finally:
+        lib.jirf_set_gemm_split_bf16(before)
+
+
 def test_hint_key_layout_matches_reference_layout():
     cfg = ho.default_config()
     net = jirf_hip.Net("HINT", cfg)
